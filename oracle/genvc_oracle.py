@@ -1,0 +1,382 @@
+"""CPU oracle for the GenVC codec-token generation hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain torch-CPU / numpy restatement of the
+reference's algorithm for the path named in BASELINE.json `north_star` (SURVEY.md
+section 8a).  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` may import it; the product (`genvc_amd/`) never does and fails loudly when
+its HIP library is missing.
+
+Pinning status -- the reference ships no tests, so pins are
+outputs of the reference's own classes run in the build container by
+`oracle/make_golden.py` and committed under `tests/golden/`:
+  * GPT prefill / decode / latent re-pass / compute_embeddings, Perceiver, content
+    DVAE + VQ, HF logits processors: PINNED against the imported reference classes.
+  * mel spectrogram: the arithmetic lives in torchaudio==2.3.0 (absent here):
+    PARITY UNPINNED; restated from torchaudio's documented algorithm and cross-checked
+    against a float64 direct DFT.
+  * sample_stream loop (stream_generator.py cannot import under transformers 5):
+    restated from stream_generator.py:809-881, the per-step processors are pinned.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  Weights are passed as a dict keyed by the reference state-dict names.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------
+# row 1: mel front-end  (utils.py:97-162; torchaudio.transforms.MelSpectrogram)
+# ---------------------------------------------------------------------------
+
+MEL = dict(n_fft=2048, hop=256, win=1024, sr=24000, f_min=0.0, f_max=8000.0, n_mels=80)
+
+
+def mel_filterbank(n_freqs=1025, f_min=0.0, f_max=8000.0, n_mels=80, sr=24000, dtype=torch.float32):
+    """torchaudio.functional.melscale_fbanks(norm="slaney", mel_scale="htk") -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sr // 2, n_freqs, dtype=dtype)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2, dtype=dtype)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.clamp(torch.min(down, up), min=0.0)
+    enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+    return fb * enorm.unsqueeze(0)
+
+
+def mel_spectrogram(wav, mel_norms, dtype=torch.float32):
+    """utils.py:150-162: log(clamp(melfb . |STFT|^2, 1e-5)) / mel_norms.  wav [B,T] -> [B,80,1+T//256]."""
+    c = MEL
+    x = wav.to(dtype)
+    window = torch.hann_window(c["win"], periodic=True, dtype=dtype)
+    spec = torch.stft(x, c["n_fft"], c["hop"], c["win"], window=window, center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2                       # [B,1025,F]
+    fb = mel_filterbank(c["n_fft"] // 2 + 1, c["f_min"], c["f_max"], c["n_mels"], c["sr"], dtype)
+    mel = torch.matmul(power.transpose(1, 2), fb).transpose(1, 2)
+    mel = torch.log(torch.clamp(mel, min=1e-5))
+    return mel / mel_norms.to(dtype).view(1, -1, 1)
+
+
+def mel_spectrogram_dft64(wav, mel_norms):
+    """Independent float64 check of `mel_spectrogram`: explicit framing + direct DFT (numpy)."""
+    c = MEL
+    x = np.asarray(wav, dtype=np.float64)
+    out = []
+    n = np.arange(c["win"])
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / c["win"])
+    k = np.arange(c["n_fft"] // 2 + 1)
+    off = (c["n_fft"] - c["win"]) // 2
+    # only the centre `win` taps of each n_fft frame are non-zero
+    ang = -2.0 * np.pi * np.outer(k, n + off) / c["n_fft"]
+    cosm, sinm = np.cos(ang), np.sin(ang)
+    fb = mel_filterbank(dtype=torch.float64).numpy()
+    for b in range(x.shape[0]):
+        xp = np.pad(x[b], c["n_fft"] // 2, mode="reflect")
+        nfr = 1 + x.shape[1] // c["hop"]
+        fr = np.stack([xp[i * c["hop"] + off:i * c["hop"] + off + c["win"]] * win for i in range(nfr)], 1)
+        power = (cosm @ fr) ** 2 + (sinm @ fr) ** 2
+        mel = fb.T @ power
+        out.append(np.log(np.maximum(mel, 1e-5)) / np.asarray(mel_norms, dtype=np.float64)[:, None])
+    return np.stack(out)
+
+
+# ---------------------------------------------------------------------------
+# row 3: Perceiver resampler  (perceiver_encoder.py:225-319, gpt.py:351-373)
+# ---------------------------------------------------------------------------
+
+def _rmsnorm(x, gamma):
+    # perceiver_encoder.py:177-179: F.normalize(x, dim=-1) * sqrt(dim) * gamma
+    return F.normalize(x, dim=-1) * (x.shape[-1] ** 0.5) * gamma
+
+
+def perceiver_forward(w, x, prefix="conditioning_perceiver.", heads=8, dim_head=64):
+    """x [B,F,dim_context] -> [B,num_latents,dim]  (PerceiverResampler.forward :265-276)."""
+    g = lambda n: w[prefix + n]
+    B = x.shape[0]
+    if prefix + "proj_context.weight" in w:
+        x = F.linear(x, g("proj_context.weight"), g("proj_context.bias"))
+    lat = g("latents").unsqueeze(0).expand(B, -1, -1)
+    depth = 0
+    while f"{prefix}layers.{depth}.0.to_q.weight" in w:
+        depth += 1
+    scale = dim_head ** -0.5
+    for l in range(depth):
+        p = f"layers.{l}."
+        # Attention.forward :305-319 with cross_attn_include_queries -> keys = [latents; context]
+        ctx = torch.cat((lat, x), dim=-2)
+        q = F.linear(lat, g(p + "0.to_q.weight"))
+        kv = F.linear(ctx, g(p + "0.to_kv.weight"))
+        k, v = kv.chunk(2, dim=-1)
+        sh = lambda t: t.reshape(B, t.shape[1], heads, dim_head).transpose(1, 2)
+        q, k, v = sh(q), sh(k), sh(v)
+        sim = torch.matmul(q, k.transpose(-1, -2)) * scale          # Attend.forward :128
+        attn = sim.softmax(dim=-1)
+        o = torch.matmul(attn, v).transpose(1, 2).reshape(B, lat.shape[1], heads * dim_head)
+        lat = F.linear(o, g(p + "0.to_out.weight")) + lat
+        # FeedForward :211-222 = Linear -> GEGLU (x, gate = chunk; gelu(gate) * x, exact erf) -> Linear
+        h = F.linear(lat, g(p + "1.0.weight"), g(p + "1.0.bias"))
+        a, gate = h.chunk(2, dim=-1)
+        h = F.gelu(gate) * a
+        lat = F.linear(h, g(p + "1.2.weight"), g(p + "1.2.bias")) + lat
+    return _rmsnorm(lat, g("norm.gamma"))
+
+
+def get_style_emb(w, mel):
+    """gpt.py:351-373 (mask=None at inference): mel [B,80,F] -> [B,d,32]."""
+    return perceiver_forward(w, mel.permute(0, 2, 1)).transpose(1, 2)
+
+
+def get_gpt_cond_latents(w, audio, mel_norms, sr=24000, length=30, chunk_length=6):
+    """trainers/hifigan_trainer.py:438-455: <=30 s, 6 s chunks, skip <0.33 s, mean over chunks -> [1,32,d]."""
+    embs = []
+    if audio.shape[1] > sr * length:
+        audio = audio[:, :sr * length]
+    for i in range(0, audio.shape[1], sr * chunk_length):
+        chunk = audio[:, i:i + sr * chunk_length]
+        if chunk.shape[-1] < sr * 0.33:
+            continue
+        embs.append(get_style_emb(w, mel_spectrogram(chunk, mel_norms)))
+    return torch.stack(embs).mean(dim=0).transpose(1, 2)
+
+
+# ---------------------------------------------------------------------------
+# row 5: content DVAE encoder + VQ  (dvae.py:252-291, 324-331, 87-93)
+# ---------------------------------------------------------------------------
+
+def dvae_encode(w, feat, prefix=""):
+    """feat [B,C,T] -> encoder output [B,T',codebook_dim] (channels last, as fed to Quantize)."""
+    x = feat
+    idx = 0
+    while f"{prefix}encoder.{idx}.0.weight" in w:                 # strided conv + ReLU stages
+        x = F.relu(F.conv1d(x, w[f"{prefix}encoder.{idx}.0.weight"], w[f"{prefix}encoder.{idx}.0.bias"],
+                            stride=2, padding=(w[f"{prefix}encoder.{idx}.0.weight"].shape[-1] - 1) // 2))
+        idx += 1
+    while f"{prefix}encoder.{idx}.net.0.weight" in w:             # ResBlock :172-184
+        p = f"{prefix}encoder.{idx}.net."
+        h = F.relu(F.conv1d(x, w[p + "0.weight"], w[p + "0.bias"], padding=1))
+        h = F.relu(F.conv1d(h, w[p + "2.weight"], w[p + "2.bias"], padding=1))
+        x = F.conv1d(h, w[p + "4.weight"], w[p + "4.bias"]) + x
+        idx += 1
+    x = F.conv1d(x, w[f"{prefix}encoder.{idx}.weight"], w[f"{prefix}encoder.{idx}.bias"])
+    return x.permute(0, 2, 1)
+
+
+def vq_indices(x, embed):
+    """Quantize.forward dvae.py:87-90: argmax(-(|x|^2 - 2 x.E + |E|^2)); first index wins ties."""
+    flat = x.reshape(-1, x.shape[-1])
+    dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ embed + embed.pow(2).sum(0, keepdim=True)
+    _, ind = (-dist).max(1)
+    return ind.view(*x.shape[:-1])
+
+
+def dvae_get_codebook_indices(w, feat, prefix=""):
+    return vq_indices(dvae_encode(w, feat, prefix), w[prefix + "codebook.embed"])
+
+
+# ---------------------------------------------------------------------------
+# rows 6-9, 12: GPT  (gpt.py, gpt_inference.py, HF GPT2Model)
+# ---------------------------------------------------------------------------
+
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def _ln(x, w, name):
+    return F.layer_norm(x, (x.shape[-1],), w[name + ".weight"], w[name + ".bias"], 1e-5)
+
+
+def compute_embeddings(w, dims, cond_latents, codes):
+    """gpt.py:572-592 -> (prefix_emb [B,P,d], fake ids int64 [B,P+1])."""
+    ids = F.pad(codes, (0, 1), value=dims["stop_text_token"])
+    ids = F.pad(ids, (1, 0), value=dims["start_text_token"])
+    emb = w["text_embedding.weight"][ids] + w["text_pos_embedding.emb.weight"][:ids.shape[1]]
+    emb = torch.cat([cond_latents, emb], dim=1)
+    fake = torch.full((emb.shape[0], emb.shape[1] + 1), 1, dtype=torch.long)
+    fake[:, -1] = dims["start_audio_token"]
+    return emb, fake
+
+
+def gpt_blocks(w, dims, x, cache=None):
+    """HF GPT2Model block stack on rows x [B,T,d]; `cache` = list of (K,V) [B,H,S,hd] or None.
+
+    Conv1D: y = x @ W[in,out] + b.  Causal within the new rows, full view of the cache.
+    Returns (ln_f(h), new_cache).
+    """
+    B, T, d = x.shape
+    H = dims["n_head"]
+    hd = d // H
+    new_cache = []
+    for l in range(dims["n_layer"]):
+        p = f"gpt.h.{l}."
+        a = _ln(x, w, p + "ln_1")
+        qkv = a @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
+        q, k, v = qkv.split(d, dim=-1)
+        sh = lambda t: t.reshape(B, T, H, hd).transpose(1, 2)
+        q, k, v = sh(q), sh(k), sh(v)
+        if cache is not None:
+            k = torch.cat([cache[l][0], k], dim=2)
+            v = torch.cat([cache[l][1], v], dim=2)
+        new_cache.append((k, v))
+        S = k.shape[2]
+        s = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)
+        if T > 1:
+            i = torch.arange(T).view(T, 1) + (S - T)
+            j = torch.arange(S).view(1, S)
+            s = s.masked_fill(j > i, torch.finfo(s.dtype).min)
+        pr = torch.softmax(s, dim=-1)
+        o = torch.matmul(pr, v).transpose(1, 2).reshape(B, T, d)
+        x = x + (o @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"])
+        m = _ln(x, w, p + "ln_2")
+        h = gelu_new(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+        x = x + (h @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"])
+    return _ln(x, w, "gpt.ln_f"), new_cache
+
+
+def head(w, h):
+    """gpt_inference.py:18,111-112: lm_head = Sequential(final_norm, mel_head) on ln_f output.
+    Returns (latent = final_norm(h), logits); the latent is what stream_generator.py:865 yields."""
+    z = _ln(h, w, "final_norm")
+    return z, F.linear(z, w["mel_head.weight"], w["mel_head.bias"])
+
+
+def gpt_prefill(w, dims, prefix_emb):
+    """gpt_inference.py:81-91: rows = [prefix | mel_embedding[start] + mel_pos[0]]; last row only."""
+    B = prefix_emb.shape[0]
+    row = w["mel_embedding.weight"][dims["start_audio_token"]] + w["mel_pos_embedding.emb.weight"][0]
+    emb = torch.cat([prefix_emb, row.view(1, 1, -1).expand(B, 1, -1)], dim=1)
+    h, cache = gpt_blocks(w, dims, emb)
+    z, logits = head(w, h[:, -1])
+    return z, logits, cache
+
+
+def gpt_decode_step(w, dims, cache, tok, j):
+    """gpt_inference.py:92-96: emb = mel_embedding[tok] + mel_pos[j], j = #acoustic positions cached."""
+    emb = (w["mel_embedding.weight"][tok] + w["mel_pos_embedding.emb.weight"][j]).unsqueeze(1)
+    h, cache = gpt_blocks(w, dims, emb, cache)
+    z, logits = head(w, h[:, -1])
+    return z, logits, cache
+
+
+def gpt_latents(w, dims, cond_latents, codes, gen_codes):
+    """GPT.forward(..., cond_latents=, return_latent=True) gpt.py:375-508 for one utterance batch
+    with full-length rows: input [cond | <s>codes</s> | start, gen, stop x4], drop last 5 -> n latents."""
+    stop_a, start_a = dims["stop_audio_token"], dims["start_audio_token"]
+    text = F.pad(codes, (0, 1), value=dims["stop_text_token"])
+    text = F.pad(text, (1, 0), value=dims["start_text_token"])
+    n = gen_codes.shape[1]
+    # code_lengths = ceil(n*1024/1024)+3 -> pad to n+3 with zeros, then stop, set_mel_padding -> stop
+    audio = torch.cat([gen_codes, torch.full((gen_codes.shape[0], 4), stop_a, dtype=gen_codes.dtype)], 1)
+    audio = F.pad(audio, (1, 0), value=start_a)
+    temb = w["text_embedding.weight"][text] + w["text_pos_embedding.emb.weight"][:text.shape[1]]
+    memb = w["mel_embedding.weight"][audio] + w["mel_pos_embedding.emb.weight"][:audio.shape[1]]
+    emb = torch.cat([cond_latents, temb, memb], dim=1)
+    h, _ = gpt_blocks(w, dims, emb)
+    enc = _ln(h[:, cond_latents.shape[1]:], w, "final_norm")
+    return enc[:, -audio.shape[1]:][:, :-5]
+
+
+# ---------------------------------------------------------------------------
+# row 10: sampling  (stream_generator.py:809-881; HF logits processors 4.33)
+# ---------------------------------------------------------------------------
+
+def rng_uniform(seed, step, row):
+    """Counter-based uniform in [0,1): the reference's torch.multinomial stream is not
+    reproducible, so the build (kernel and oracle alike) draws u from this hash."""
+    m64 = (1 << 64) - 1
+    x = (seed * 0x9E3779B97F4A7C15 + step * 0xBF58476D1CE4E5B9 + row * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & m64
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & m64
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & m64
+    x ^= x >> 31
+    return float(np.float32((x >> 40) * (2.0 ** -24)))
+
+
+def process_logits(logits, ids, rep_penalty=2.0, temperature=0.85, top_k=15, top_p=0.85):
+    """RepetitionPenalty -> Temperature -> TopK(min_keep 1) -> TopP(min_keep 1); logits [B,V], ids [B,S]."""
+    s = logits.clone()
+    g = torch.gather(s, 1, ids)
+    g = torch.where(g < 0, g * rep_penalty, g / rep_penalty)
+    s.scatter_(1, ids, g)
+    s = s / temperature
+    if top_k and top_k > 0:
+        k = min(top_k, s.shape[-1])
+        kth = torch.topk(s, k)[0][..., -1, None]
+        s = s.masked_fill(s < kth, -float("inf"))
+    if top_p is not None and top_p < 1.0:
+        sl, si = torch.sort(s, descending=False)
+        cp = sl.softmax(dim=-1).cumsum(dim=-1)
+        rem = cp <= (1 - top_p)
+        rem[..., -1:] = False
+        s = s.masked_fill(rem.scatter(1, si, rem), -float("inf"))
+    return s
+
+
+def sample_from_scores(scores, seed, step):
+    """softmax + inverse-CDF draw in vocabulary order: first i with cdf[i] >= u * cdf[-1]."""
+    probs = torch.softmax(scores, dim=-1)
+    out = torch.empty(scores.shape[0], dtype=torch.long)
+    for b in range(scores.shape[0]):
+        cdf = torch.cumsum(probs[b].double(), 0)
+        u = rng_uniform(seed, step, b) * float(cdf[-1])
+        nz = (probs[b] > 0)
+        idx = int(torch.nonzero((cdf >= u) & nz)[0]) if u > 0 else int(torch.nonzero(nz)[0])
+        out[b] = idx
+    return out
+
+
+def generate(w, dims, cond_latents, codes, sampling, max_new=None, seed=0, stop_on_eos=True):
+    """gpt.generate / get_generator loop (gpt.py:594-621 + stream_generator.py:809-881).
+
+    Returns (tokens int64 [B,n] incl. the EOS step, latents [B,n,d], logits of every step [n,B,V]).
+    Finished rows emit the pad (=stop) token; the EOS step's latent is yielded too (:865)."""
+    stop = dims["stop_audio_token"]
+    max_new = dims["max_gen_mel_tokens"] if max_new is None else max_new
+    prefix, ids = compute_embeddings(w, dims, cond_latents, codes)
+    B = ids.shape[0]
+    unfinished = torch.ones(B, dtype=torch.long)
+    z, logits, cache = gpt_prefill(w, dims, prefix)
+    toks, lats, all_logits = [], [], []
+    for step in range(max_new):
+        all_logits.append(logits)
+        scores = process_logits(logits, ids, sampling["repetition_penalty"], sampling["temperature"],
+                                sampling["top_k"], sampling["top_p"])
+        nxt = sample_from_scores(scores, seed, step)
+        nxt = nxt * unfinished + stop * (1 - unfinished)
+        toks.append(nxt); lats.append(z)
+        ids = torch.cat([ids, nxt[:, None]], dim=-1)
+        unfinished = unfinished * (nxt != stop).long()
+        if (stop_on_eos and unfinished.max() == 0) or step == max_new - 1:
+            break
+        z, logits, cache = gpt_decode_step(w, dims, cache, nxt, step + 1)
+    return torch.stack(toks, 1), torch.stack(lats, 1), torch.stack(all_logits, 0)
+
+
+# ---------------------------------------------------------------------------
+# row 13: harness pieces  (inference/inference_utils.py)
+# ---------------------------------------------------------------------------
+
+def segment_source(n_samples, seg_len_s, sr=16000):
+    """inference_utils.py:34-50: [(start, end, padded_len)] per segment; last padded to >= 0.32 s."""
+    seg = int(seg_len_s * sr)
+    min_len = int(0.32 * sr)
+    out = []
+    for i in range(0, n_samples, seg):
+        end = min(i + seg, n_samples)
+        out.append((i, end, max(end - i, min_len) if end == n_samples else end - i))
+    return out
+
+
+def handle_chunks(wav_gen, wav_overlap, overlap_len=1024):
+    """inference_utils.py:4-21 (cross-fade of streamed vocoder chunks)."""
+    chunk = wav_gen[:-overlap_len].clone()
+    if wav_overlap is not None:
+        if overlap_len > len(chunk):
+            return wav_gen[-overlap_len:], None
+        fade_in = chunk[:overlap_len] * torch.linspace(0.0, 1.0, overlap_len)
+        chunk[:overlap_len] = wav_overlap * torch.linspace(1.0, 0.0, overlap_len) + fade_in
+    return chunk, wav_gen[-overlap_len:]

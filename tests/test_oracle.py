@@ -1,0 +1,137 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference's own
+classes (oracle/make_golden.py).  These pin the oracle before any GPU test trusts it."""
+import numpy as np
+import pytest
+import torch
+
+from genvc_amd import config as gcfg
+from genvc_amd import synth
+from oracle import genvc_oracle as O
+
+GREEDY = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
+_cache = {}
+
+
+def weights(model_args, seed):
+    key = (model_args["gpt_layers"], model_args["gpt_n_model_channels"], seed)
+    if key not in _cache:
+        dims = gcfg.gpt_dims(model_args)
+        _cache.clear()
+        _cache[key] = (dims, synth.make_weights(seed, synth.gpt_weight_spec(dims)))
+    return _cache[key]
+
+
+def inputs(g, dims):
+    s, B, Tc = int(g["in_seed"]), int(g["B"]), int(g["Tc"])
+    cond = synth.uniform(s, "cond_latents", (B, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(s, "content_codes", (B, Tc), 256)
+    return cond, codes
+
+
+def check_gpt(g, model_args):
+    dims, w = weights(model_args, int(g["seed"]))
+    cond, codes = inputs(g, dims)
+    prefix, fake = O.compute_embeddings(w, dims, cond, codes)
+    assert np.array_equal(fake.numpy(), g["fake_ids"])
+    assert abs(prefix.double().sum().item() - float(g["prefix_sum"])) < 1e-3
+    np.testing.assert_allclose(prefix[:, -3:, :16].numpy(), g["prefix_slice"], atol=1e-6)
+    n = g["tokens"].shape[1]
+    toks, lats, logits = O.generate(w, dims, cond, codes, GREEDY, max_new=n)
+    assert np.array_equal(toks.numpy(), g["tokens"])                       # bit-exact ids
+    rows = g["logit_rows"]
+    np.testing.assert_allclose(logits[rows].numpy(), g["logits"], atol=1e-4)
+    np.testing.assert_allclose(lats[:, :, :32].numpy(), g["latents_slice"], atol=1e-4)
+    # row 12: teacher-forced latent re-pass == decode-time latents
+    gen = toks[0][toks[0] != dims["stop_audio_token"]].unsqueeze(0)
+    rel = O.gpt_latents(w, dims, cond[:1], codes[:1], gen)
+    assert rel.shape[1] == gen.shape[1]
+    np.testing.assert_allclose(rel[:, :, :32].numpy(), g["relatents"], atol=1e-4)
+    np.testing.assert_allclose(rel[:, :gen.shape[1]].numpy(), lats[:1, :gen.shape[1]].numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["gpt_tiny", "gpt_tiny_b1"])
+def test_gpt_tiny_vs_reference(gold, name):
+    check_gpt(gold(name), gcfg.TINY_MODEL_ARGS)
+
+
+def test_gpt_eos_vs_reference(gold):
+    g = gold("gpt_eos")
+    dims, w = weights(gcfg.TINY_MODEL_ARGS, int(g["seed"]))
+    w = dict(w)
+    w["mel_head.bias"] = w["mel_head.bias"].clone()
+    w["mel_head.bias"][1025] = float(g["stop_bias"])
+    cond = synth.uniform(int(g["seed"]), "cond_latents", (2, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(int(g["seed"]), "content_codes", (2, 9), 256)
+    toks, lats, _ = O.generate(w, dims, cond, codes, GREEDY, max_new=40)
+    assert np.array_equal(toks.numpy(), g["tokens"])        # stops when every row hit 1025; pads after
+    np.testing.assert_allclose(lats[:, :, :32].numpy(), g["latents_slice"], atol=1e-4)
+
+
+def test_gpt_full_vs_reference(gold):
+    check_gpt(gold("gpt_full"), gcfg.DEFAULT_MODEL_ARGS)
+
+
+def test_perceiver_vs_reference(gold):
+    g = gold("perceiver")
+    seed = int(g["seed"])
+    for tag, margs, wseed in (("tiny", gcfg.TINY_MODEL_ARGS, 3), ("full", gcfg.DEFAULT_MODEL_ARGS, 1)):
+        dims = gcfg.gpt_dims(margs)
+        w = synth.make_weights(wseed, synth.perceiver_weight_spec(dims["d_model"], prefix="conditioning_perceiver."))
+        for B, Fr in ((1, 282), (2, 563)):
+            mel = synth.uniform(seed, f"mel_{B}_{Fr}", (B, 80, Fr), 1.0)
+            y = O.get_style_emb(w, mel)
+            np.testing.assert_allclose(y.numpy(), g[f"{tag}_{B}_{Fr}"], atol=2e-5)
+
+
+def test_dvae_vs_reference(gold):
+    g = gold("dvae")
+    seed = int(g["seed"])
+    for tag, c in (("tiny", gcfg.TINY_CONTENT_DVAE), ("full", gcfg.DEFAULT_CONTENT_DVAE)):
+        w = synth.make_weights(seed, synth.dvae_weight_spec(c))
+        for B, T in ((1, 49), (2, 299), (1, 199), (1, 16)):
+            feat = synth.uniform(seed, f"feat_{B}_{T}", (B, c["num_channels"], T), 1.0)
+            codes = O.dvae_get_codebook_indices(w, feat)
+            assert codes.shape == g[f"{tag}_codes_{B}_{T}"].shape            # 49->13, 299->75, 199->50
+            assert np.array_equal(codes.numpy(), g[f"{tag}_codes_{B}_{T}"])
+            enc = O.dvae_encode(w, feat)
+            np.testing.assert_allclose(enc[:, :, :16].numpy(), g[f"{tag}_enc_{B}_{T}"], atol=1e-5)
+
+
+def test_sampler_processors_vs_hf(gold):
+    g = gold("sampler")
+    logits = synth.uniform(int(g["seed"]), "logits", (4, 1026), 2.0)
+    ids = torch.from_numpy(g["ids"])
+    for k, p in ((1, 0.85), (15, 0.85), (50, 0.85), (15, 1.0), (1026, 0.5)):
+        s = O.process_logits(logits, ids, 2.0, 0.85, k, p)
+        ref = g[f"scores_k{k}_p{int(p * 100)}"]
+        assert np.array_equal(np.isinf(s.numpy()), np.isinf(ref))
+        m = ~np.isinf(ref)
+        np.testing.assert_allclose(s.numpy()[m], ref[m], rtol=1e-6)
+    # top_k=1 leaves exactly one candidate = argmax of the penalised logits
+    s = O.process_logits(logits, ids, 2.0, 0.85, 1, 0.85)
+    assert (torch.isfinite(s).sum(-1) == 1).all()
+
+
+def test_mel_fp32_vs_float64_dft():
+    """mel is 'parity unpinned' (torchaudio absent): cross-check the fp32 restatement against an
+    independent float64 direct-DFT formulation, within the north_star tolerance 1e-4."""
+    mel_norms = torch.from_numpy(np.load("genvc_amd/assets/mel_stats.npy"))
+    wav = synth.synth_audio(21, "ref3s", 72000)
+    m32 = O.mel_spectrogram(wav, mel_norms)
+    assert m32.shape == (1, 80, 282)
+    m64 = O.mel_spectrogram_dft64(wav.numpy(), mel_norms.numpy())
+    np.testing.assert_allclose(m32.numpy(), m64, atol=1e-4)
+    for T, Fr in ((144000, 563), (96000, 376), (98835, 387)):
+        assert O.mel_spectrogram(synth.synth_audio(1, "x", T), mel_norms).shape[-1] == Fr
+
+
+def test_segmentation_and_chunks():
+    assert O.segment_source(160000, 6.0) == [(0, 96000, 96000), (96000, 160000, 64000)]
+    assert O.segment_source(160000, 1.0)[-1] == (144000, 160000, 16000)
+    assert O.segment_source(97000, 6.0)[-1] == (96000, 97000, 5120)          # padded to 0.32 s
+    w1 = torch.arange(8192, dtype=torch.float32)
+    c1, ov = O.handle_chunks(w1, None)
+    assert c1.shape[0] == 7168 and ov.shape[0] == 1024
+    c2, ov2 = O.handle_chunks(w1 + 1.0, ov)
+    assert c2.shape[0] == 7168
+    assert abs(float(c2[0]) - float(ov[0])) < 1e-6                            # fade starts at the old tail
