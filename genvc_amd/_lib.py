@@ -1,0 +1,109 @@
+"""ctypes binding of libgenvc_hip.so (include/genvc_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgenvc_hip.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+
+
+class GptDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_layer", "d_model", "n_head", "vocab", "max_mel_pos", "max_text_pos",
+                                         "n_text", "max_seq", "max_slots", "max_rows")]
+
+
+class SampleParams(C.Structure):
+    _fields_ = [("repetition_penalty", C.c_float), ("temperature", C.c_float), ("top_p", C.c_float),
+                ("top_k", C.c_int32), ("eos_token", C.c_int32), ("vocab", C.c_int32), ("seed", C.c_uint64)]
+
+
+class PerceiverDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim", "depth", "dim_context", "num_latents", "dim_head", "heads",
+                                         "ff_mult", "max_batch", "max_frames")]
+
+
+class DvaeDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("channels", "hidden_dim", "num_layers", "num_resnet_blocks", "kernel_size",
+                                         "codebook_dim", "num_tokens", "max_batch", "max_frames")]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "gvc_version": (C.c_int, []),
+    "gvc_last_error": (C.c_char_p, []),
+    "gvc_gpt_create": (C.c_int, [C.POINTER(GptDims), C.POINTER(_P)]),
+    "gvc_gpt_destroy": (C.c_int, [_P]),
+    "gvc_gpt_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "gvc_gpt_missing_weights": (C.c_int, [_P]),
+    "gvc_gpt_prefix_embeddings": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "gvc_gpt_prefill": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_gpt_decode_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
+    "gvc_gpt_reset_slots": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "gvc_gpt_latents": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "gvc_sample": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32, _P, _P]),
+    "gvc_gpt_generate": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32,
+                                   C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
+    "gvc_perceiver_create": (C.c_int, [C.POINTER(PerceiverDims), C.POINTER(_P)]),
+    "gvc_perceiver_destroy": (C.c_int, [_P]),
+    "gvc_perceiver_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "gvc_perceiver_missing_weights": (C.c_int, [_P]),
+    "gvc_perceiver_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "gvc_mel_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                 c_f32p, C.POINTER(_P)]),
+    "gvc_mel_destroy": (C.c_int, [_P]),
+    "gvc_mel_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_dvae_create": (C.c_int, [C.POINTER(DvaeDims), C.POINTER(_P)]),
+    "gvc_dvae_destroy": (C.c_int, [_P]),
+    "gvc_dvae_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "gvc_dvae_missing_weights": (C.c_int, [_P]),
+    "gvc_dvae_encode": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_vq_argmin": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class GenvcHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names declared in include/genvc_hip.h (used by the CPU test that checks the .so exports them)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GenvcHipError(f"{LIB_PATH} not found: build it with `python -m genvc_amd.build` "
+                                "(there is no CPU fallback for the product path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            if not hasattr(L, name): continue  # TEMP until all kernels land
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().gvc_last_error().decode(errors="replace")
+        raise GenvcHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

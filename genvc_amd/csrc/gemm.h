@@ -1,0 +1,69 @@
+// fp32 MFMA GEMM for the batched (prefill-shaped) parts of the path:
+//   C[m][n] = epilogue( sum_k A[m][k] * Wt[n][k] )      A: [M][lda], Wt: [N][ldw], both K-contiguous
+// v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation (bitwise an fmaf chain), 157 TFLOP/s peak.
+// Tile 64x64x32, 4 waves (2x2), one 32x32 accumulator per wave, LDS double-buffered and padded to
+// 36-float rows so the ds_read_b128 fragment reads are bank-conflict-free.  A lane reads 4 consecutive
+// k of its row at once and feeds 4 MFMAs with the k-permutation {t, t+4} (A and B use the same one).
+// Split-K (gridDim.z = batch*SK) writes raw partials; k_splitk_epilogue finishes deterministically.
+#pragma once
+#include "common.h"
+
+namespace gvc {
+
+enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_RELU = 2 };
+
+struct GemmEpi {
+    const float* bias;       // [N] or null
+    int act;                 // GemmAct
+    const float* resid;      // [M][ldr] or null (may alias C for in-place residual)
+    int ldr;
+    long long resid_batch_stride;
+    // GPT QKV scatter (prefill): n < d -> q[m][n]; else K/V cache rows
+    int qkv;                 // 1 -> scatter mode, C is the q buffer [M][d]
+    int d, n_head, head_dim, max_seq, T;
+    float* kcache; float* vcache;
+    const int32_t* slots;
+};
+
+struct GemmArgs {
+    const float* A; int lda; long long a_batch_stride;
+    const float* Wt; int ldw;
+    float* C; int ldc; long long c_batch_stride;
+    int M, N, K;
+    int SK;                  // split-K factor; >1: C unused, partials to `work`
+    float* work;             // [batch][SK][M][N]
+    GemmEpi e;
+};
+
+__device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, int n, float v) {
+    const GemmEpi& e = G.e;
+    if (e.bias) v += e.bias[n];
+    if (e.act == ACT_GELU_NEW) v = gelu_new(v);
+    else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    if (e.qkv) {
+        const int which = n / e.d;
+        const int c = n - which * e.d;
+        if (which == 0) {
+            G.C[(size_t)m * G.ldc + c] = v;
+        } else {
+            const int b = m / e.T, t = m - b * e.T;
+            const int slot = e.slots[b];
+            const int h = c / e.head_dim, j = c - h * e.head_dim;
+            float* cache = which == 1 ? e.kcache : e.vcache;
+            cache[(((size_t)slot * e.n_head + h) * e.max_seq + t) * e.head_dim + j] = v;
+        }
+        return;
+    }
+    if (e.resid) v += e.resid[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
+    G.C[batch * G.c_batch_stride + (size_t)m * G.ldc + n] = v;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G);
+__global__ void k_splitk_epilogue(const GemmArgs G);
+
+// chooses the split-K factor from the shape; `work_cap` = capacity of G.work in floats
+int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s);
+
+}  // namespace gvc

@@ -1,0 +1,655 @@
+// GPT context of libgenvc_hip: weight binding/repack, KV cache, prefill, decode step, latent re-pass,
+// graph-replayed generation loop.  Reference seams: layers/gpt.py, layers/gpt_inference.py (see
+// include/genvc_hip.h for the line-level mapping).
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm.h"
+#include "gpt_kernels.h"
+#include "sampler.h"
+
+namespace gvc {
+
+// ---------------------------------------------------------------------------------------------
+// row kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const float* w1, const float* b1,
+                          const float* w2, const float* b2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = src + (size_t)row * d;
+    float* y = dst + (size_t)row * d;
+    const float inv_d = 1.0f / (float)d;
+    for (int pass = 0; pass < (w2 ? 2 : 1); ++pass) {
+        const float* in = pass == 0 ? x : y;
+        const float* gw = pass == 0 ? w1 : w2;
+        const float* gb = pass == 0 ? b1 : b2;
+        float s = 0.f;
+        for (int k = lane * 4; k < d; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(in + k);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+        for (int k = lane * 4; k < d; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(in + k);
+            const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+        for (int k = lane * 4; k < d; k += 256) {
+            float4 v = *reinterpret_cast<const float4*>(in + k);
+            const float4 g = *reinterpret_cast<const float4*>(gw + k);
+            const float4 c = *reinterpret_cast<const float4*>(gb + k);
+            v.x = (v.x - mean) * rstd * g.x + c.x; v.y = (v.y - mean) * rstd * g.y + c.y;
+            v.z = (v.z - mean) * rstd * g.z + c.z; v.w = (v.w - mean) * rstd * g.w + c.w;
+            *reinterpret_cast<float4*>(y + k) = v;
+        }
+    }
+}
+
+__global__ void k_embed_rows(float* x, const float* prefix_emb, int B, int T, int P, int d, const float* mel_emb,
+                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok) {
+    const int row = blockIdx.x;
+    const int b = row / T, t = row - b * T;
+    float* dst = x + (size_t)row * d;
+    if (t < P) {
+        const float* src = prefix_emb + ((size_t)b * P + t) * d;
+        for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4)
+            *reinterpret_cast<float4*>(dst + k) = *reinterpret_cast<const float4*>(src + k);
+    } else {
+        const int i = t - P;
+        const int tok = i == 0 ? start_tok : (i <= n ? codes[(size_t)b * n + i - 1] : stop_tok);
+        const float* e = mel_emb + (size_t)tok * d;
+        const float* p = mel_pos + (size_t)i * d;
+        for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4) {
+            const float4 a = *reinterpret_cast<const float4*>(e + k);
+            const float4 c = *reinterpret_cast<const float4*>(p + k);
+            *reinterpret_cast<float4*>(dst + k) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        }
+    }
+}
+
+__global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const int32_t* codes, int B, int Tc,
+                              int d, const float* text_emb, const float* text_pos, int start_text,
+                              int stop_text) {
+    const int P = n_cond + Tc + 2;
+    const int row = blockIdx.x;
+    const int b = row / P, t = row - b * P;
+    float* dst = out + (size_t)row * d;
+    if (t < n_cond) {
+        const float* src = cond + ((size_t)b * n_cond + t) * d;
+        for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4)
+            *reinterpret_cast<float4*>(dst + k) = *reinterpret_cast<const float4*>(src + k);
+    } else {
+        const int i = t - n_cond;
+        const int id = i == 0 ? start_text : (i <= Tc ? codes[(size_t)b * Tc + i - 1] : stop_text);
+        const float* e = text_emb + (size_t)id * d;
+        const float* p = text_pos + (size_t)i * d;
+        for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4) {
+            const float4 a = *reinterpret_cast<const float4*>(e + k);
+            const float4 c = *reinterpret_cast<const float4*>(p + k);
+            *reinterpret_cast<float4*>(dst + k) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+        }
+    }
+}
+
+__global__ void k_set_state(GptState st, const int32_t* slots, int B, int seq_len, int mel_pos) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        st.seq_len[slots[b]] = seq_len;
+        st.mel_pos[slots[b]] = mel_pos;
+    }
+}
+
+__global__ void k_gather_rows(const float* src, float* dst, int B, int T, int off, int n, int d) {
+    const int row = blockIdx.x;
+    const int b = row / n, i = row - b * n;
+    const float* s = src + ((size_t)b * T + off + i) * d;
+    float* o = dst + (size_t)row * d;
+    for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4)
+        *reinterpret_cast<float4*>(o + k) = *reinterpret_cast<const float4*>(s + k);
+}
+
+__global__ void k_transpose(const float* src, float* dst, int K, int N) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int k = k0 + r, n = n0 + threadIdx.x;
+        if (k < K && n < N) tile[r][threadIdx.x] = src[(size_t)k * N + n];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int n = n0 + r, k = k0 + threadIdx.x;
+        if (k < K && n < N) dst[(size_t)n * K + k] = tile[threadIdx.x][r];
+    }
+}
+
+// parameters of one gvc_gpt_generate call, resident on the device so the captured step graph
+// is independent of them
+struct GenCall {
+    SampleCall sc;
+    int32_t slots[64];
+};
+
+__global__ void k_set_gen_call(GenCall* dst, SampleCall sc, const int32_t* slots, int B) {
+    if (threadIdx.x == 0) dst->sc = sc;
+    if (threadIdx.x < B) dst->slots[threadIdx.x] = slots[threadIdx.x];
+}
+
+}  // namespace gvc
+
+using namespace gvc;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct GptLayer {
+    float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *p2_w, *p2_b;
+};
+
+struct gvc_gpt {
+    gvc_gpt_dims dm;
+    int hd = 0, n_cu = 256;
+    float* wbase = nullptr;           // one allocation for all weights
+    float *mel_emb, *mel_pos, *text_emb, *text_pos, *lnf_w, *lnf_b, *fn_w, *fn_b, *head_w, *head_b;
+    std::vector<GptLayer> layers;
+    std::map<std::string, int> bound;  // name -> 1 once bound
+    int n_expected = 0;
+    float* kv = nullptr;              // [L][2][slots][H][max_seq][hd]
+    size_t kv_layer_stride = 0;       // floats per (layer, k|v)
+    float *x = nullptr, *a = nullptr, *q = nullptr, *h = nullptr, *part = nullptr, *work = nullptr;
+    long long work_cap = 0;
+    float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
+    int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step
+    GptState st;
+    int32_t *tok_buf = nullptr, *step_ctr = nullptr;
+    GenCall* gen_call = nullptr;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, hipGraphExec_t> graphs;   // B -> step graph
+};
+
+static int gemv_init();
+
+static int alloc_f(float** p, size_t n) {
+    GVC_CHECK_HIP(hipMalloc((void**)p, n * sizeof(float)));
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
+    GVC_REQUIRE(dims && out, GVC_ERR_ARG, "gvc_gpt_create: null argument");
+    const gvc_gpt_dims& D = *dims;
+    GVC_REQUIRE(D.n_layer > 0 && D.n_head > 0 && D.d_model % D.n_head == 0, GVC_ERR_ARG, "bad GPT dims");
+    const int hd = D.d_model / D.n_head;
+    GVC_REQUIRE(D.d_model == 256 || D.d_model == 1024, GVC_ERR_UNSUPPORTED,
+                "d_model %d unsupported (kernels instantiated for 256 and 1024)", D.d_model);
+    GVC_REQUIRE(hd == 64 || hd == 256, GVC_ERR_UNSUPPORTED, "head_dim %d unsupported (64 or 256)", hd);
+    GVC_REQUIRE(D.max_slots >= 1 && D.max_slots <= 64, GVC_ERR_ARG, "max_slots must be in [1,64]");
+    GVC_REQUIRE(D.max_rows >= D.max_slots, GVC_ERR_ARG, "max_rows must be >= max_slots");
+    auto* c = new gvc_gpt();
+    c->dm = D;
+    c->hd = hd;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    GVC_CHECK_HIP(hipGetDevice(&dev));
+    GVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    const size_t d = D.d_model, L = D.n_layer, V = D.vocab;
+    const size_t per_layer = 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d;
+    const size_t total = V * d + (size_t)D.max_mel_pos * d + (size_t)D.n_text * d + (size_t)D.max_text_pos * d +
+                         4 * d + V * d + V + 64 + L * per_layer;
+    int rc = alloc_f(&c->wbase, total + 64);
+    if (rc) { delete c; return rc; }
+    float* p = c->wbase;
+    auto take = [&](size_t n) { float* r = p; p += (n + 3) & ~(size_t)3; return r; };
+    c->mel_emb = take(V * d); c->mel_pos = take((size_t)D.max_mel_pos * d);
+    c->text_emb = take((size_t)D.n_text * d); c->text_pos = take((size_t)D.max_text_pos * d);
+    c->lnf_w = take(d); c->lnf_b = take(d); c->fn_w = take(d); c->fn_b = take(d);
+    c->head_w = take(V * d); c->head_b = take(V);
+    c->layers.resize(L);
+    for (auto& ly : c->layers) {
+        ly.ln1_w = take(d); ly.ln1_b = take(d); ly.qkv_w = take(3 * d * d); ly.qkv_b = take(3 * d);
+        ly.proj_w = take(d * d); ly.proj_b = take(d); ly.ln2_w = take(d); ly.ln2_b = take(d);
+        ly.fc_w = take(4 * d * d); ly.fc_b = take(4 * d); ly.p2_w = take(4 * d * d); ly.p2_b = take(d);
+    }
+    c->n_expected = 10 + 12 * (int)L;
+
+    c->kv_layer_stride = (size_t)D.max_slots * D.n_head * D.max_seq * hd;
+    const size_t rows = D.max_rows;
+    c->work_cap = 8ll << 20;
+    if ((rc = alloc_f(&c->kv, 2 * L * c->kv_layer_stride)) || (rc = alloc_f(&c->x, rows * d)) ||
+        (rc = alloc_f(&c->a, rows * d)) || (rc = alloc_f(&c->q, rows * d)) || (rc = alloc_f(&c->h, rows * 4 * d)) ||
+        (rc = alloc_f(&c->part, (size_t)D.max_slots * D.n_head * kAttnChunks * (hd + 4))) ||
+        (rc = alloc_f(&c->work, (size_t)c->work_cap)) || (rc = alloc_f(&c->logits, (size_t)D.max_slots * V)) ||
+        (rc = alloc_f(&c->latent, (size_t)D.max_slots * d))) {
+        gvc_gpt_destroy(c);
+        return rc;
+    }
+    const size_t nstate = 3 * (size_t)D.max_slots + 4;
+    GVC_CHECK_HIP(hipMalloc((void**)&c->state, nstate * sizeof(int32_t)));
+    GVC_CHECK_HIP(hipMemset(c->state, 0, nstate * sizeof(int32_t)));
+    c->st.seq_len = c->state;
+    c->st.mel_pos = c->state + D.max_slots;
+    c->tok_buf = c->state + 2 * D.max_slots;
+    c->step_ctr = c->state + 3 * D.max_slots;
+    GVC_CHECK_HIP(hipMalloc((void**)&c->gen_call, sizeof(GenCall)));
+    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    if ((rc = gemv_init())) { gvc_gpt_destroy(c); return rc; }
+    *out = c;
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
+    if (!c) return GVC_OK;
+    for (auto& kvp : c->graphs) hipGraphExecDestroy(kvp.second);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    for (void* p : {(void*)c->wbase, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
+                    (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state,
+                    (void*)c->gen_call})
+        if (p) hipFree(p);
+    delete c;
+    return GVC_OK;
+}
+
+static int copy_w(float* dst, const float* src, int64_t numel, int64_t expect, const char* name, hipStream_t s) {
+    GVC_REQUIRE(numel == expect, GVC_ERR_ARG, "%s: expected %lld elements, got %lld", name, (long long)expect,
+                (long long)numel);
+    GVC_CHECK_HIP(hipMemcpyAsync(dst, src, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return GVC_OK;
+}
+
+// HF Conv1D weight [K][N] -> row-per-output [N][K]
+static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N, const char* name, hipStream_t s) {
+    GVC_REQUIRE(numel == (int64_t)K * N, GVC_ERR_ARG, "%s: expected %lld elements, got %lld", name,
+                (long long)K * N, (long long)numel);
+    hipLaunchKernelGGL(k_transpose, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(32, 8), 0, s, src, dst, K, N);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* src, int64_t numel, gvc_stream sv) {
+    GVC_REQUIRE(c && name && src, GVC_ERR_ARG, "gvc_gpt_bind_weight: null argument");
+    hipStream_t s = (hipStream_t)sv;
+    const int64_t d = c->dm.d_model, V = c->dm.vocab;
+    std::string n(name);
+    int rc = GVC_OK;
+    bool known = true;
+    if (n == "mel_embedding.weight") rc = copy_w(c->mel_emb, src, numel, V * d, name, s);
+    else if (n == "mel_pos_embedding.emb.weight") rc = copy_w(c->mel_pos, src, numel, c->dm.max_mel_pos * d, name, s);
+    else if (n == "text_embedding.weight") rc = copy_w(c->text_emb, src, numel, c->dm.n_text * d, name, s);
+    else if (n == "text_pos_embedding.emb.weight") rc = copy_w(c->text_pos, src, numel, c->dm.max_text_pos * d, name, s);
+    else if (n == "gpt.ln_f.weight") rc = copy_w(c->lnf_w, src, numel, d, name, s);
+    else if (n == "gpt.ln_f.bias") rc = copy_w(c->lnf_b, src, numel, d, name, s);
+    else if (n == "final_norm.weight") rc = copy_w(c->fn_w, src, numel, d, name, s);
+    else if (n == "final_norm.bias") rc = copy_w(c->fn_b, src, numel, d, name, s);
+    else if (n == "mel_head.weight") rc = copy_w(c->head_w, src, numel, V * d, name, s);
+    else if (n == "mel_head.bias") rc = copy_w(c->head_b, src, numel, V, name, s);
+    else if (n.rfind("gpt.h.", 0) == 0) {
+        const size_t dot = n.find('.', 6);
+        GVC_REQUIRE(dot != std::string::npos, GVC_ERR_ARG, "malformed weight name %s", name);
+        const int li = atoi(n.substr(6, dot - 6).c_str());
+        const std::string rest = n.substr(dot + 1);
+        GVC_REQUIRE(li >= 0 && li < c->dm.n_layer, GVC_ERR_ARG, "%s: layer out of range", name);
+        GptLayer& ly = c->layers[li];
+        if (rest == "ln_1.weight") rc = copy_w(ly.ln1_w, src, numel, d, name, s);
+        else if (rest == "ln_1.bias") rc = copy_w(ly.ln1_b, src, numel, d, name, s);
+        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s);
+        else if (rest == "attn.c_attn.bias") rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s);
+        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s);
+        else if (rest == "attn.c_proj.bias") rc = copy_w(ly.proj_b, src, numel, d, name, s);
+        else if (rest == "ln_2.weight") rc = copy_w(ly.ln2_w, src, numel, d, name, s);
+        else if (rest == "ln_2.bias") rc = copy_w(ly.ln2_b, src, numel, d, name, s);
+        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s);
+        else if (rest == "mlp.c_fc.bias") rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s);
+        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s);
+        else if (rest == "mlp.c_proj.bias") rc = copy_w(ly.p2_b, src, numel, d, name, s);
+        else known = false;   // attn.bias / attn.masked_bias buffers of 4.33-era checkpoints
+    } else {
+        known = false;        // text_head.*, conditioning_perceiver.*, gpt.wte.* ... (strict=False)
+    }
+    if (rc == GVC_OK && known) c->bound[n] = 1;
+    return rc;
+}
+
+extern "C" int gvc_gpt_missing_weights(gvc_gpt* c) {
+    if (!c) return -1;
+    return c->n_expected - (int)c->bound.size();
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+template <int PRO, int EPI>
+static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
+    const int NI = (A.K < 1024 ? A.K : 1024) / 256;
+    GVC_REQUIRE(NI == 1 || NI == 4, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", A.K);
+    A.ksplit = A.K / (NI * 256);
+    GVC_REQUIRE(A.ksplit * NI * 256 == A.K, GVC_ERR_UNSUPPORTED, "gemv: K=%d not a multiple of %d", A.K, NI * 256);
+    const int items = A.N * A.ksplit;
+    int wpb = cdiv(items, c->n_cu);
+    if (wpb < 4) wpb = 4;
+    if (wpb > 16) wpb = 16;
+    wpb = cdiv(wpb, A.ksplit) * A.ksplit;
+    GVC_REQUIRE(wpb <= 16, GVC_ERR_UNSUPPORTED, "gemv: ksplit %d too large", A.ksplit);
+    A.wpb = wpb;
+    A.B = B;
+    const int BT = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
+    const int grid = cdiv(items, wpb);
+    const size_t lds = ((size_t)BT * A.K + (size_t)wpb * BT) * sizeof(float);
+#define GVC_GEMV_CASE(bt, ni)                                                    \
+    if (BT == bt && NI == ni) {                                                  \
+        hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI>), dim3(grid), dim3(wpb * 64), lds, s, A); \
+        GVC_LAUNCH_CHECK();                                                      \
+        return GVC_OK;                                                           \
+    }
+    GVC_GEMV_CASE(1, 1) GVC_GEMV_CASE(1, 4) GVC_GEMV_CASE(2, 1) GVC_GEMV_CASE(2, 4)
+    GVC_GEMV_CASE(4, 1) GVC_GEMV_CASE(4, 4) GVC_GEMV_CASE(8, 1) GVC_GEMV_CASE(8, 4)
+#undef GVC_GEMV_CASE
+    set_error("gemv: no instantiation for BT=%d NI=%d", BT, NI);
+    return GVC_ERR_UNSUPPORTED;
+}
+
+// dynamic LDS above 64 KiB needs an opt-in per kernel; done once at context creation (never while a
+// stream is capturing)
+template <int PRO, int EPI>
+static int gemv_allow_big_lds() {
+#define GVC_GEMV_ATTR(bt, ni)                                                                              \
+    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemv<bt, ni, PRO, EPI>,                               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    GVC_GEMV_ATTR(1, 1) GVC_GEMV_ATTR(1, 4) GVC_GEMV_ATTR(2, 1) GVC_GEMV_ATTR(2, 4)
+    GVC_GEMV_ATTR(4, 1) GVC_GEMV_ATTR(4, 4) GVC_GEMV_ATTR(8, 1) GVC_GEMV_ATTR(8, 4)
+#undef GVC_GEMV_ATTR
+    return GVC_OK;
+}
+
+static int gemv_init() {
+    int rc;
+    if ((rc = gemv_allow_big_lds<PRO_LN, EPI_QKV>())) return rc;
+    if ((rc = gemv_allow_big_lds<PRO_MERGE, EPI_RESID>())) return rc;
+    if ((rc = gemv_allow_big_lds<PRO_LN, EPI_GELU>())) return rc;
+    if ((rc = gemv_allow_big_lds<PRO_COPY, EPI_RESID>())) return rc;
+    return gemv_allow_big_lds<PRO_LN2X, EPI_LOGITS>();
+}
+
+static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
+    GemvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.d = c->dm.d_model;
+    A.x = c->x + (size_t)row0 * A.d;
+    A.x_stride = 1;
+    A.x_off = 0;
+    A.n_head = c->dm.n_head;
+    A.head_dim = c->hd;
+    A.max_seq = c->dm.max_seq;
+    A.max_mel_pos = c->dm.max_mel_pos;
+    A.slots = slots;
+    A.st = c->st;
+    A.mel_emb = c->mel_emb;
+    A.mel_pos_tab = c->mel_pos;
+    return A;
+}
+
+static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s) {
+    dim3 grid(chunks, c->dm.n_head, rows);
+    if (c->hd == 256) {
+        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, dim3(256), 0, s, T);
+        else hipLaunchKernelGGL((k_attention<256, false>), grid, dim3(256), 0, s, T);
+    } else {
+        if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, dim3(256), 0, s, T);
+        else hipLaunchKernelGGL((k_attention<64, false>), grid, dim3(256), 0, s, T);
+    }
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
+    AttnArgs T;
+    memset(&T, 0, sizeof(T));
+    T.q_stride = c->dm.d_model;
+    T.kbase = c->kv + (size_t)(2 * layer) * c->kv_layer_stride;
+    T.vbase = c->kv + (size_t)(2 * layer + 1) * c->kv_layer_stride;
+    T.k_batch_stride = (long long)c->dm.n_head * c->dm.max_seq * c->hd;
+    T.k_head_stride = (long long)c->dm.max_seq * c->hd;
+    T.k_row_stride = c->hd;
+    T.slots = slots;
+    T.causal = 1;
+    T.scale = 1.0f / sqrtf((float)c->hd);
+    return T;
+}
+
+// one decode step for a group of <= 8 streams whose scratch rows start at row0
+static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
+                        float* latent_out, int32_t* step_ctr, hipStream_t s) {
+    const int d = c->dm.d_model;
+    int rc;
+    float* qb = c->q + (size_t)row0 * d;
+    float* hb = c->h + (size_t)row0 * 4 * d;
+    float* pb = c->part + (size_t)row0 * c->dm.n_head * kAttnChunks * (c->hd + 4);
+    for (int l = 0; l < c->dm.n_layer; ++l) {
+        const GptLayer& ly = c->layers[l];
+        GemvArgs A = base_args(c, slots, row0);
+        A.Wt = ly.qkv_w; A.bias = ly.qkv_b; A.N = 3 * d; A.K = d;
+        A.ln_w = ly.ln1_w; A.ln_b = ly.ln1_b; A.embed = l == 0; A.tok_in = tok_in;
+        A.out = qb;
+        A.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
+        A.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+        if ((rc = launch_gemv<PRO_LN, EPI_QKV>(c, A, B, s))) return rc;
+
+        AttnArgs T = gpt_attn_args(c, l, slots);
+        T.q = qb; T.T = 1; T.base_len = c->st.seq_len; T.out = pb;
+        if ((rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
+
+        A = base_args(c, slots, row0);
+        A.Wt = ly.proj_w; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
+        if ((rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
+
+        A = base_args(c, slots, row0);
+        A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
+        if ((rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
+
+        A = base_args(c, slots, row0);
+        A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
+        if ((rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
+    }
+    GemvArgs A = base_args(c, slots, row0);
+    A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+    A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
+    A.out = logits_out; A.latent_out = latent_out; A.advance = 1; A.step_ctr = step_ctr;
+    return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
+}
+
+static int check_ready(gvc_gpt* c) {
+    GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
+    GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
+                gvc_gpt_missing_weights(c));
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, const int32_t* tok_in,
+                                   float* logits_out, float* latent_out, gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "decode_step: B=%d outside [1,%d]", B, c->dm.max_slots);
+    hipStream_t s = (hipStream_t)sv;
+    for (int g = 0; g < B; g += 8) {
+        const int Bg = B - g < 8 ? B - g : 8;
+        if ((rc = decode_group(c, slots + g, Bg, g, tok_in + g, logits_out + (size_t)g * c->dm.vocab,
+                               latent_out + (size_t)g * c->dm.d_model, nullptr, s)))
+            return rc;
+    }
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_reset_slots(gvc_gpt* c, const int32_t* slots, int32_t B, gvc_stream sv) {
+    GVC_REQUIRE(c && slots && B >= 1, GVC_ERR_ARG, "reset_slots: bad argument");
+    hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)sv, c->st, slots, B, 0, 0);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_prefix_embeddings(gvc_gpt* c, const float* cond, int32_t n_cond, const int32_t* codes,
+                                         int32_t B, int32_t Tc, int32_t start_text, int32_t stop_text, float* out,
+                                         gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    GVC_REQUIRE(Tc + 2 <= c->dm.max_text_pos, GVC_ERR_ARG, "prefix: %d content codes exceed text positions", Tc);
+    const int P = n_cond + Tc + 2;
+    hipLaunchKernelGGL(k_prefix_rows, dim3(B * P), dim3(256), 0, (hipStream_t)sv, out, cond, n_cond, codes, B, Tc,
+                       c->dm.d_model, c->text_emb, c->text_pos, start_text, stop_text);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+// block stack over B*T rows already in c->x; K/V of every row go to the slots' cache (positions 0..T-1)
+static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s) {
+    const int d = c->dm.d_model, rows = B * T;
+    int rc;
+    for (int l = 0; l < c->dm.n_layer; ++l) {
+        const GptLayer& ly = c->layers[l];
+        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, ly.ln1_w, ly.ln1_b,
+                           (const float*)nullptr, (const float*)nullptr);
+        GVC_LAUNCH_CHECK();
+        GemmArgs G;
+        memset(&G, 0, sizeof(G));
+        G.A = c->a; G.lda = d; G.Wt = ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+        G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
+        G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots;
+        G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
+        G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+
+        AttnArgs At = gpt_attn_args(c, l, slots);
+        At.q = c->q; At.T = T; At.base_len = nullptr; At.out = c->a; At.out_stride = d;
+        if ((rc = launch_attention(c, At, 1, rows, true, s))) return rc;
+
+        memset(&G, 0, sizeof(G));
+        G.A = c->a; G.lda = d; G.Wt = ly.proj_w; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
+        G.work = c->work; G.e.bias = ly.proj_b; G.e.resid = c->x; G.e.ldr = d;
+        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+
+        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, ly.ln2_w, ly.ln2_b,
+                           (const float*)nullptr, (const float*)nullptr);
+        GVC_LAUNCH_CHECK();
+        memset(&G, 0, sizeof(G));
+        G.A = c->a; G.lda = d; G.Wt = ly.fc_w; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+        G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW;
+        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+
+        memset(&G, 0, sizeof(G));
+        G.A = c->h; G.lda = 4 * d; G.Wt = ly.p2_w; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
+        G.work = c->work; G.e.bias = ly.p2_b; G.e.resid = c->x; G.e.ldr = d;
+        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+    }
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_prefill(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
+                               int32_t start_tok, float* logits_out, float* latent_out, gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const int T = P + 1, d = c->dm.d_model;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "prefill: B=%d outside [1,%d]", B, c->dm.max_slots);
+    GVC_REQUIRE(P >= 0 && B * T <= c->dm.max_rows, GVC_ERR_ARG, "prefill: %d rows exceed max_rows %d", B * T, c->dm.max_rows);
+    GVC_REQUIRE(T < c->dm.max_seq, GVC_ERR_ARG, "prefill: %d rows exceed max_seq %d", T, c->dm.max_seq);
+    hipStream_t s = (hipStream_t)sv;
+    if (!logits_out) logits_out = c->logits;      // staging of the generation loop
+    if (!latent_out) latent_out = c->latent;
+    hipLaunchKernelGGL(k_embed_rows, dim3(B * T), dim3(256), 0, s, c->x, prefix_emb, B, T, P, d, c->mel_emb, c->mel_pos,
+                       (const int32_t*)nullptr, 0, start_tok, start_tok);
+    GVC_LAUNCH_CHECK();
+    if ((rc = run_rows(c, slots, B, T, s))) return rc;
+    for (int g = 0; g < B; g += 8) {
+        const int Bg = B - g < 8 ? B - g : 8;
+        GemvArgs A = base_args(c, slots + g, 0);
+        A.x = c->x + (size_t)g * T * d; A.x_stride = T; A.x_off = T - 1;
+        A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+        A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
+        A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 0;
+        if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;
+    }
+    hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, T, 1);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
+                               const int32_t* gen_codes, int32_t n, int32_t start_tok, int32_t stop_tok, float* out,
+                               gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const int T = P + n + 5, d = c->dm.d_model;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && n >= 1, GVC_ERR_ARG, "latents: bad B=%d n=%d", B, n);
+    GVC_REQUIRE(B * T <= c->dm.max_rows, GVC_ERR_ARG, "latents: %d rows exceed max_rows %d", B * T, c->dm.max_rows);
+    GVC_REQUIRE(T < c->dm.max_seq && n + 5 <= c->dm.max_mel_pos, GVC_ERR_ARG, "latents: sequence too long");
+    hipStream_t s = (hipStream_t)sv;
+    hipLaunchKernelGGL(k_embed_rows, dim3(B * T), dim3(256), 0, s, c->x, prefix_emb, B, T, P, d, c->mel_emb, c->mel_pos,
+                       gen_codes, n, start_tok, stop_tok);
+    GVC_LAUNCH_CHECK();
+    if ((rc = run_rows(c, slots, B, T, s))) return rc;
+    hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(B * T, 4)), dim3(256), 0, s, c->x, c->a, B * T, d, c->lnf_w, c->lnf_b,
+                       c->fn_w, c->fn_b);
+    GVC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_gather_rows, dim3(B * n), dim3(256), 0, s, c->a, out, B, T, P, n, d);
+    GVC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, 0, 0);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
+// ---------------------------------------------------------------------------------------------
+static int build_step_graph(gvc_gpt* c, int B, hipGraphExec_t* out) {
+    hipStream_t cs = c->cap_stream;
+    GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
+    for (int g = 0; g < B && rc == GVC_OK; g += 8) {
+        const int Bg = B - g < 8 ? B - g : 8;
+        const bool last = g + 8 >= B;
+        rc = decode_group(c, c->gen_call->slots + g, Bg, g, c->tok_buf + g, c->logits + (size_t)g * c->dm.vocab,
+                          c->latent + (size_t)g * c->dm.d_model, last ? c->step_ctr : nullptr, cs);
+    }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc != GVC_OK) {
+        if (graph) hipGraphDestroy(graph);
+        return rc;
+    }
+    GVC_CHECK_HIP(e);
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    GVC_CHECK_HIP(e);
+    return GVC_OK;
+}
+
+extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
+                                int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
+                                int32_t n_steps, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
+                                int32_t lat_stride, gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && p && n_steps >= 0, GVC_ERR_ARG, "generate: bad argument");
+    GVC_REQUIRE(p->vocab == c->dm.vocab, GVC_ERR_ARG, "generate: vocab mismatch");
+    hipStream_t s = (hipStream_t)sv;
+    SampleCall sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.logits = c->logits; sc.B = B; sc.ids = ids; sc.ids_stride = ids_stride; sc.ids_len = ids_len;
+    sc.finished = finished; sc.p = *p; sc.step = 0; sc.step_ptr = c->step_ctr; sc.tok_out = c->tok_buf;
+    sc.tokens_out = tokens_out; sc.tok_stride = tok_stride; sc.i0 = i0; sc.latent_src = c->latent;
+    sc.latents_out = latents_out; sc.lat_stride = lat_stride; sc.d = c->dm.d_model;
+    GVC_CHECK_HIP(hipMemsetAsync(c->step_ctr, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_set_gen_call, dim3(1), dim3(64), 0, s, c->gen_call, sc, slots, B);
+    GVC_LAUNCH_CHECK();
+    auto it = c->graphs.find(B);
+    if (it == c->graphs.end()) {
+        hipGraphExec_t ge;
+        if ((rc = build_step_graph(c, B, &ge))) return rc;
+        it = c->graphs.emplace(B, ge).first;
+    }
+    for (int i = 0; i < n_steps; ++i) GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
+    return GVC_OK;
+}
+

@@ -1,0 +1,421 @@
+// Device kernels of the GPT hot path (decode-step GEMVs, attention, row ops).
+// Layouts (all fp32):
+//   weights     row-per-output "Wt[N][K]" (HF Conv1D [in,out] is transposed once at bind time), so a
+//               wave streams one output row as 1 KiB-per-instruction coalesced float4 loads;
+//   KV cache    [layer][k|v][slot][head][max_seq][head_dim]: a key/value row is head_dim*4 contiguous
+//               bytes (1 KiB at head_dim 256) and rows of one head are adjacent;
+//   residual x  [row][d]; q [row][d]; mlp hidden [row][4d];
+//   attention partials [row][head][chunk][head_dim + 4]  (o[hd], m, l, pad) for split-key decode.
+#pragma once
+#include "common.h"
+
+namespace gvc {
+
+constexpr int kAttnChunks = 8;   // key-axis split of one decode attention row (flash-decoding style)
+
+struct GptState {                // device-resident step state, one entry per slot
+    int32_t* seq_len;            // cached positions
+    int32_t* mel_pos;            // index into mel_pos_embedding of the next decode input
+};
+
+enum Prologue { PRO_LN = 0, PRO_MERGE = 1, PRO_COPY = 2, PRO_LN2X = 3 };
+enum Epilogue { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
+
+struct GemvArgs {
+    // GEMV operand
+    const float* Wt;     // [N][K]
+    const float* bias;   // [N]
+    int N, K;
+    int wpb;             // waves per block
+    int ksplit;          // waves per output row (each owns K/ksplit consecutive inputs)
+    int B;               // live streams (<= BT)
+    // row addressing of the residual stream: row(b) = b * x_stride + x_off
+    float* x;
+    int x_stride, x_off;
+    int d;
+    // prologue operands
+    const float* ln_w; const float* ln_b;       // PRO_LN / first LN of PRO_LN2X
+    const float* ln2_w; const float* ln2_b;     // second LN of PRO_LN2X
+    const float* in;                            // PRO_COPY: [B][K]; PRO_MERGE: attention partials
+    int embed;                                  // PRO_LN: 1 -> x = mel_emb[tok] + mel_pos[pos] first
+    const float* mel_emb; const float* mel_pos_tab; const int32_t* tok_in;
+    int n_head, head_dim;
+    // epilogue operands
+    float* out;                                 // q [B][d] / hidden [B][N] / logits [B][N]
+    float* latent_out;                          // PRO_LN2X: [B][d]
+    float* kcache; float* vcache;               // this layer's [slot][head][max_seq][hd]
+    int max_seq, max_mel_pos;
+    const int32_t* slots;
+    GptState st;
+    int advance;                                // EPI_LOGITS: 1 -> seq_len++, mel_pos++ per slot
+    int32_t* step_ctr;                          // EPI_LOGITS: nullable, ++ once per launch (generation loop)
+};
+
+// ---------------------------------------------------------------------------------------------
+// decode-step GEMV: out[b][n] = epilogue( sum_k Wt[n][k] * a[b][k] + bias[n] ),  a = prologue(x)
+//
+// One wave owns one (output row, K-segment of 256*NI inputs).  Program order per wave is
+//   prologue input loads (L2-resident, tiny)  ->  all NI float4 weight loads (1 KiB per
+//   wave-instruction, straight to VGPRs: a GEMV operand is streamed once and never shared, so an LDS
+//   round trip would be pure overhead)  ->  prologue math (LayerNorm / attention merge) while the
+//   HBM stream is in flight  ->  LDS-staged input vectors read back as conflict-free ds_read_b128.
+// vmcnt retires in order, hence the small prologue loads are issued BEFORE the weight stream.
+// HBM-bound: N*K*4 algorithmic bytes per launch.  BT = streams per launch (padded), B live ones.
+// ---------------------------------------------------------------------------------------------
+template <int BT, int NI, int PRO, int EPI>
+__global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = A.wpb;
+    constexpr int KSEG = NI * 256;
+    float* a_lds = smem;                       // [BT][K]
+    float* red = smem + BT * A.K;              // [wpb][BT] cross-wave partial sums (ksplit > 1)
+
+    const int item = blockIdx.x * nwave + wave;
+    const int row = item / A.ksplit;
+    const int seg = item - row * A.ksplit;
+    const bool live = row < A.N;
+    const float* wp = A.Wt + (size_t)(live ? row : 0) * A.K + seg * KSEG + lane * 4;
+    float4 w[NI];
+
+    // LayerNorm (once or twice) of v in registers, result to LDS (and the latent output)
+    auto ln_store = [&](int b, float4 (&v)[NI]) {
+        const float inv_d = 1.0f / (float)A.d;
+#pragma unroll
+        for (int pass = 0; pass < (PRO == PRO_LN2X ? 2 : 1); ++pass) {
+            const float* gw = pass == 0 ? A.ln_w : A.ln2_w;
+            const float* gb = pass == 0 ? A.ln_b : A.ln2_b;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            const float mean = wave_sum(s) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float4 g = *reinterpret_cast<const float4*>(gw + i * 256 + lane * 4);
+                const float4 c = *reinterpret_cast<const float4*>(gb + i * 256 + lane * 4);
+                v[i].x = (v[i].x - mean) * rstd * g.x + c.x;
+                v[i].y = (v[i].y - mean) * rstd * g.y + c.y;
+                v[i].z = (v[i].z - mean) * rstd * g.z + c.z;
+                v[i].w = (v[i].w - mean) * rstd * g.w + c.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            *reinterpret_cast<float4*>(a_lds + b * A.K + i * 256 + lane * 4) = v[i];
+            if (PRO == PRO_LN2X && blockIdx.x == 0)
+                *reinterpret_cast<float4*>(A.latent_out + (size_t)b * A.d + i * 256 + lane * 4) = v[i];
+        }
+    };
+    // residual-stream row of stream b (layer 0 of a decode step builds it from the embeddings)
+    auto load_x = [&](int b, float4 (&v)[NI]) {
+        float* xr = A.x + (size_t)(b * A.x_stride + A.x_off) * A.d;
+        if (PRO == PRO_LN && A.embed) {
+            const int slot = A.slots[b];
+            const float* e = A.mel_emb + (size_t)A.tok_in[b] * A.d;
+            const float* p = A.mel_pos_tab + (size_t)A.st.mel_pos[slot] * A.d;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float4 ev = *reinterpret_cast<const float4*>(e + i * 256 + lane * 4);
+                const float4 pv = *reinterpret_cast<const float4*>(p + i * 256 + lane * 4);
+                v[i] = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
+                if (blockIdx.x == 0) *reinterpret_cast<float4*>(xr + i * 256 + lane * 4) = v[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        }
+    };
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+    };
+
+    if constexpr (PRO == PRO_LN || PRO == PRO_LN2X) {
+        // one wave per stream (K == d == 256*NI); the first stream's row is requested before the weights
+        float4 v[NI];
+        const bool mine = wave < A.B;
+        if (mine) load_x(wave, v);
+        load_w();
+        if (mine) ln_store(wave, v);
+        for (int b = wave + nwave; b < A.B; b += nwave) { load_x(b, v); ln_store(b, v); }
+        for (int b = A.B + wave; b < BT; b += nwave)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                *reinterpret_cast<float4*>(a_lds + b * A.K + i * 256 + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if constexpr (PRO == PRO_COPY) {
+        // a = in[b][0..K): every thread moves float4s; BT*K/4 of them, at most 8 per thread in flight
+        const int total4 = BT * A.K / 4;
+        constexpr int CU = 8;
+        bool first = true;
+        for (int base = threadIdx.x; base < total4; base += blockDim.x * CU) {
+            float4 t[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int idx = base + u * blockDim.x;
+                const int b = (idx * 4) / A.K;
+                t[u] = (idx < total4 && b < A.B) ? *reinterpret_cast<const float4*>(A.in + (size_t)idx * 4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (first) { load_w(); first = false; }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int idx = base + u * blockDim.x;
+                if (idx < total4) *reinterpret_cast<float4*>(a_lds + (size_t)idx * 4) = t[u];
+            }
+        }
+        if (first) load_w();
+    } else {  // PRO_MERGE: combine the kAttnChunks partial softmax states of each head
+        load_w();
+        const int pstride = A.head_dim + 4;   // (o[hd], m, l, pad): keeps float4 alignment
+        for (int b = wave; b < BT; b += nwave) {
+            for (int k = lane * 4; k < A.K; k += 256) {
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < A.B) {
+                    const int h = k / A.head_dim;
+                    const int j = k - h * A.head_dim;
+                    const float* pp = A.in + ((size_t)(b * A.n_head + h) * kAttnChunks) * pstride;
+                    float mc[kAttnChunks], lc[kAttnChunks];
+                    float4 oc[kAttnChunks];
+#pragma unroll
+                    for (int c = 0; c < kAttnChunks; ++c) {
+                        mc[c] = pp[c * pstride + A.head_dim];
+                        lc[c] = pp[c * pstride + A.head_dim + 1];
+                        oc[c] = *reinterpret_cast<const float4*>(pp + c * pstride + j);
+                    }
+                    float m = mc[0];
+#pragma unroll
+                    for (int c = 1; c < kAttnChunks; ++c) m = fmaxf(m, mc[c]);
+                    float L = 0.f;
+#pragma unroll
+                    for (int c = 0; c < kAttnChunks; ++c) {
+                        const float wgt = __expf(mc[c] - m);
+                        L += wgt * lc[c];
+                        o.x += wgt * oc[c].x; o.y += wgt * oc[c].y; o.z += wgt * oc[c].z; o.w += wgt * oc[c].w;
+                    }
+                    const float inv = 1.0f / L;
+                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                }
+                *reinterpret_cast<float4*>(a_lds + b * A.K + k) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dot products against the staged vectors ----
+    float acc[BT];
+    const float* ap = a_lds + seg * KSEG + lane * 4;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 av = *reinterpret_cast<const float4*>(ap + b * A.K + i * 256);
+            s = fmaf(w[i].x, av.x, s); s = fmaf(w[i].y, av.y, s);
+            s = fmaf(w[i].z, av.z, s); s = fmaf(w[i].w, av.w, s);
+        }
+        acc[b] = wave_sum(s);
+    }
+    if (A.ksplit > 1) {      // combine the K-segments of a row (adjacent waves of this block)
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) red[wave * BT + b] = acc[b];
+        }
+        __syncthreads();
+        if (seg == 0) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                float s = 0.f;
+                for (int j = 0; j < A.ksplit; ++j) s += red[(wave + j) * BT + b];
+                acc[b] = s;
+            }
+        }
+    }
+
+    // ---- epilogue: lane b finishes stream b ----
+    if (live && seg == 0) {
+        float val = 0.f;
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+            if (lane == b) val = acc[b];
+        if (lane < A.B) {
+            const int b = lane;
+            val += A.bias[row];
+            if constexpr (EPI == EPI_QKV) {
+                const int which = row / A.d;
+                const int c = row - which * A.d;
+                if (which == 0) {
+                    A.out[(size_t)b * A.d + c] = val;
+                } else {
+                    const int slot = A.slots[b];
+                    const int h = c / A.head_dim;
+                    const int j = c - h * A.head_dim;
+                    float* cache = which == 1 ? A.kcache : A.vcache;
+                    cache[(((size_t)slot * A.n_head + h) * A.max_seq + A.st.seq_len[slot]) * A.head_dim + j] = val;
+                }
+            } else if constexpr (EPI == EPI_RESID) {
+                float* xr = A.x + (size_t)(b * A.x_stride + A.x_off) * A.d;
+                xr[row] += val;
+            } else if constexpr (EPI == EPI_GELU) {
+                A.out[(size_t)b * A.N + row] = gelu_new(val);
+            } else {
+                A.out[(size_t)b * A.N + row] = val;
+            }
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+        // the slot's cache grew by one position; the last cache row is re-used once the slot is full
+        if (A.advance && blockIdx.x == 0 && threadIdx.x < A.B) {
+            const int slot = A.slots[threadIdx.x];
+            if (A.st.seq_len[slot] < A.max_seq - 1) A.st.seq_len[slot] += 1;
+            if (A.st.mel_pos[slot] < A.max_mel_pos - 1) A.st.mel_pos[slot] += 1;
+        }
+        if (A.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *A.step_ctr += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention over a cached key range with online softmax.
+//   grid (chunks, heads, rows); 256 threads.  A key/value row is HD floats: HD/4 lanes cover it with
+//   float4 loads (a wave handles 64/(HD/4) keys per instruction); K and V rows of a key are fetched
+//   together so a chunk costs one memory round trip.  Each lane-group keeps a running (m, l, o) state,
+//   the block merges them through LDS.  DIRECT: one chunk, normalised output row; otherwise the
+//   (o, m, l) partial of the chunk is stored for the consumer GEMV's merge prologue.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q;            // [rows][q_stride]; head h at + h*HD
+    int q_stride;
+    const float* kbase;        // GPT: layer K cache [slot][head][max_seq][HD]; generic: see k_* strides
+    const float* vbase;
+    long long k_batch_stride;  // floats between batch elements (GPT: slot stride)
+    long long k_head_stride;   // floats between heads
+    int k_row_stride;          // floats between consecutive keys
+    int T;                     // rows per batch element (row = b*T + t)
+    const int32_t* slots;      // nullable: batch index -> slot
+    const int32_t* base_len;   // nullable: per-slot cached length before this call
+    int causal;                // 1: keys [0, base + t + 1); 0: keys [0, n_keys)
+    int n_keys;
+    float scale;
+    float* out;                // DIRECT: [rows][out_stride] ; else partials [rows][heads][chunks][HD+4]
+    int out_stride;
+};
+
+template <int HD, bool DIRECT>
+__global__ __launch_bounds__(256) void k_attention(const AttnArgs A) {
+    constexpr int LPK = HD / 4;          // lanes per key
+    constexpr int KPW = 64 / LPK;        // keys per wave-instruction
+    constexpr int NG = 4 * KPW;          // softmax states per block
+    __shared__ float m_s[NG], l_s[NG];
+    __shared__ __attribute__((aligned(16))) float o_s[NG][HD];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kl = lane / LPK;                 // key sub-slot inside the wave
+    const int dl = (lane % LPK) * 4;           // first dim owned by the lane
+    const int chunk = blockIdx.x, h = blockIdx.y, row = blockIdx.z;
+    const int nchunk = gridDim.x, nhead = gridDim.y;
+    const int b = row / A.T, t = row - b * A.T;
+    const int bi = A.slots ? A.slots[b] : b;
+    const int base = A.base_len ? A.base_len[bi] : 0;
+    const int nk = A.causal ? base + t + 1 : A.n_keys;
+    const int cs = (nk + nchunk - 1) / nchunk;
+    const int k0 = chunk * cs;
+    const int k1 = min(nk, k0 + cs);
+
+    const float4 q4 = *reinterpret_cast<const float4*>(A.q + (size_t)row * A.q_stride + h * HD + dl);
+    const float* kp = A.kbase + bi * A.k_batch_stride + h * A.k_head_stride + dl;
+    const float* vp = A.vbase + bi * A.k_batch_stride + h * A.k_head_stride + dl;
+
+    float m = -INFINITY, l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;
+    for (int kb = k0 + wave * KPW + kl; kb < k1 + (U * 4 * KPW); kb += U * 4 * KPW) {
+        if (kb - kl - wave * KPW >= k1) break;           // uniform per block iteration
+        float4 kv[U], vv[U];
+        float s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = kb + u * 4 * KPW;
+            const bool ok = key < k1;
+            const size_t off = (size_t)(ok ? key : k0) * A.k_row_stride;
+            kv[u] = *reinterpret_cast<const float4*>(kp + off);
+            vv[u] = *reinterpret_cast<const float4*>(vp + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float d = dot4(q4, kv[u]);
+            if constexpr (LPK == 64) d = wave_sum(d);
+            else d = row16_sum(d);                         // LPK == 16
+            s[u] = (kb + u * 4 * KPW < k1) ? d * A.scale : -INFINITY;
+        }
+        float mn = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[u]);
+        if (mn > -INFINITY) {
+            const float alpha = __expf(m - mn);            // m = -inf -> 0
+            l *= alpha; o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = __expf(s[u] - mn);         // masked keys: exp(-inf) = 0
+                l += p;
+                o.x = fmaf(p, vv[u].x, o.x); o.y = fmaf(p, vv[u].y, o.y);
+                o.z = fmaf(p, vv[u].z, o.z); o.w = fmaf(p, vv[u].w, o.w);
+            }
+            m = mn;
+        }
+    }
+    const int g = wave * KPW + kl;
+    if ((lane % LPK) == 0) { m_s[g] = m; l_s[g] = l; }
+    *reinterpret_cast<float4*>(&o_s[g][dl]) = o;
+    __syncthreads();
+    if (threadIdx.x < HD) {
+        const int j = threadIdx.x;
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) M = fmaxf(M, m_s[i]);
+        float L = 0.f, acc = 0.f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const float wgt = __expf(m_s[i] - M);
+                L += wgt * l_s[i];
+                acc += wgt * o_s[i][j];
+            }
+        }
+        if constexpr (DIRECT) {
+            A.out[(size_t)row * A.out_stride + h * HD + j] = acc / L;
+        } else {
+            float* pp = A.out + (((size_t)row * nhead + h) * nchunk + chunk) * (HD + 4);
+            pp[j] = acc;
+            if (j == 0) { pp[HD] = M; pp[HD + 1] = L; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row kernels for the prefill / re-pass path (one wave per row of d floats)
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (optionally twice: ln_f then final_norm) of rows src -> dst
+__global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const float* w1, const float* b1,
+                          const float* w2, const float* b2);
+// build GPT input rows: t < P -> prefix_emb[b][t]; else mel_embedding[tok] + mel_pos[t - P]
+//   tok: t == P -> start_tok; 1 <= t-P <= n -> codes[b][t-P-1]; beyond -> stop_tok
+__global__ void k_embed_rows(float* x, const float* prefix_emb, int B, int T, int P, int d, const float* mel_emb,
+                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok);
+// prefix rows of GPT.compute_embeddings
+__global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const int32_t* codes, int B, int Tc,
+                              int d, const float* text_emb, const float* text_pos, int start_text,
+                              int stop_text);
+__global__ void k_set_state(GptState st, const int32_t* slots, int B, int seq_len, int mel_pos);
+// gather rows [b][off .. off+n) of src [B][T][d] into dst [B][n][d]
+__global__ void k_gather_rows(const float* src, float* dst, int B, int T, int off, int n, int d);
+// transpose Conv1D weight [K][N] -> [N][K] (LDS-tiled, 32x32)
+__global__ void k_transpose(const float* src, float* dst, int K, int N);
+
+}  // namespace gvc

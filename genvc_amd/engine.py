@@ -1,0 +1,117 @@
+"""Thin Python owners of the libgenvc_hip contexts.  torch supplies device memory and the stream;
+all arithmetic runs in the HIP library."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "need contiguous fp32 CUDA tensor"
+    return t
+
+
+def _i32(t):
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous(), "need contiguous int32 CUDA tensor"
+    return t
+
+
+def sample_params(sampling, vocab, eos, seed=0):
+    return _lib.SampleParams(float(sampling["repetition_penalty"]), float(sampling["temperature"]),
+                             float(sampling["top_p"]), int(sampling["top_k"]), int(eos), int(vocab), int(seed))
+
+
+class GptEngine:
+    """KV-cached GPT-2 stack of GenVC (reference layers/gpt.py + layers/gpt_inference.py)."""
+
+    def __init__(self, dims, max_slots=8, max_rows=2048, max_seq=None):
+        self.dims = dict(dims)
+        self.d = dims["d_model"]
+        self.V = dims["num_audio_tokens"]
+        self.max_slots = max_slots
+        max_seq = max_seq or ((dims["max_seq"] + 63) // 64) * 64
+        cd = _lib.GptDims(dims["n_layer"], dims["d_model"], dims["n_head"], dims["num_audio_tokens"],
+                          dims["max_mel_pos"], dims["max_text_pos"], dims["number_text_tokens"], max_seq,
+                          max_slots, max_rows)
+        self._h = C.c_void_p()
+        check(lib().gvc_gpt_create(C.byref(cd), C.byref(self._h)), "gvc_gpt_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_gpt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights, prefix=""):
+        """weights: name -> CUDA fp32 tensor, named as the reference GPT state dict."""
+        for name, t in weights.items():
+            if not name.startswith(prefix) or not torch.is_tensor(t) or not t.is_floating_point():
+                continue
+            t = _f32(t.detach().to(torch.float32).contiguous())
+            check(lib().gvc_gpt_bind_weight(self._h, name[len(prefix):].encode(), ptr(t), t.numel(), stream()),
+                  f"bind {name}")
+        torch.cuda.current_stream().synchronize()      # sources may be temporaries
+        missing = lib().gvc_gpt_missing_weights(self._h)
+        if missing:
+            raise _lib.GenvcHipError(f"{missing} GPT weight tensors missing after bind")
+
+    def prefix_embeddings(self, cond_latents, codes):
+        B, n_cond, _ = cond_latents.shape
+        Tc = codes.shape[1]
+        out = torch.empty(B, n_cond + Tc + 2, self.d, device=cond_latents.device, dtype=torch.float32)
+        check(lib().gvc_gpt_prefix_embeddings(self._h, ptr(_f32(cond_latents)), n_cond, ptr(_i32(codes)), B, Tc,
+                                              self.dims["start_text_token"], self.dims["stop_text_token"],
+                                              ptr(out), stream()), "prefix_embeddings")
+        return out
+
+    def prefill(self, slots, prefix_emb, want_outputs=True):
+        B, P, _ = prefix_emb.shape
+        logits = latent = None
+        if want_outputs:
+            logits = torch.empty(B, self.V, device=prefix_emb.device, dtype=torch.float32)
+            latent = torch.empty(B, self.d, device=prefix_emb.device, dtype=torch.float32)
+        check(lib().gvc_gpt_prefill(self._h, ptr(_i32(slots)), B, ptr(_f32(prefix_emb)), P,
+                                    self.dims["start_audio_token"], ptr(logits), ptr(latent), stream()), "prefill")
+        return logits, latent
+
+    def decode_step(self, slots, tok, logits=None, latent=None):
+        B = slots.shape[0]
+        if logits is None:
+            logits = torch.empty(B, self.V, device=slots.device, dtype=torch.float32)
+            latent = torch.empty(B, self.d, device=slots.device, dtype=torch.float32)
+        check(lib().gvc_gpt_decode_step(self._h, ptr(_i32(slots)), B, ptr(_i32(tok)), ptr(logits), ptr(latent),
+                                        stream()), "decode_step")
+        return logits, latent
+
+    def reset(self, slots):
+        check(lib().gvc_gpt_reset_slots(self._h, ptr(_i32(slots)), slots.shape[0], stream()), "reset_slots")
+
+    def latents(self, slots, prefix_emb, gen_codes):
+        B, P, _ = prefix_emb.shape
+        n = gen_codes.shape[1]
+        out = torch.empty(B, n, self.d, device=prefix_emb.device, dtype=torch.float32)
+        check(lib().gvc_gpt_latents(self._h, ptr(_i32(slots)), B, ptr(_f32(prefix_emb)), P, ptr(_i32(gen_codes)), n,
+                                    self.dims["start_audio_token"], self.dims["stop_audio_token"], ptr(out),
+                                    stream()), "latents")
+        return out
+
+    def sample(self, logits, ids, ids_len, finished, params, step):
+        B = logits.shape[0]
+        tok = torch.empty(B, device=logits.device, dtype=torch.int32)
+        check(lib().gvc_sample(ptr(_f32(logits)), B, ptr(_i32(ids)), ids.shape[1], ptr(_i32(ids_len)),
+                               ptr(_i32(finished)), C.byref(params), step, ptr(tok), stream()), "sample")
+        return tok
+
+    def generate(self, slots, ids, ids_len, finished, params, i0, n_steps, tokens_out, latents_out):
+        B = slots.shape[0]
+        check(lib().gvc_gpt_generate(self._h, ptr(_i32(slots)), B, ptr(_i32(ids)), ids.shape[1], ptr(_i32(ids_len)),
+                                     ptr(_i32(finished)), C.byref(params), i0, n_steps, ptr(_i32(tokens_out)),
+                                     tokens_out.shape[1], ptr(latents_out),
+                                     latents_out.shape[1] if latents_out is not None else 0, stream()), "generate")

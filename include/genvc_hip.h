@@ -1,0 +1,208 @@
+/*
+ * genvc_hip.h -- C ABI of libgenvc_hip.so: the MI355X (gfx950) implementation of GenVC's
+ * autoregressive codec-token generation hot path.
+ *
+ * The reference (caizexin/GenVC) is pure Python and has no FFI layer of its own; the seam this
+ * library sits behind is the duck-typed object API that inference/inference_utils.py consumes
+ * (SURVEY.md section 8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repo).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C symbols, no C++ types or exceptions across the boundary;
+ *   - every function returns 0 on success or a negative GVC_ERR_* code; the message of the
+ *     last failure on the calling thread is available from gvc_last_error();
+ *   - every launch is asynchronous on the caller's stream (a hipStream_t passed as void*);
+ *     no hidden synchronisation or allocation after *_create / *_bind_*;
+ *   - tensor arguments are raw DEVICE pointers borrowed from the caller (fp32 unless stated,
+ *     row-major, contiguous); index arrays are DEVICE int32; the library frees only what it
+ *     allocated in *_create;
+ *   - a context is bound to the device that was current at *_create and must not be used
+ *     from two host threads at once; contexts are independent of each other.
+ */
+#ifndef GENVC_HIP_H
+#define GENVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GVC_OK 0
+#define GVC_ERR_ARG (-1)          /* bad argument / shape */
+#define GVC_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define GVC_ERR_STATE (-3)        /* weights missing, cache overflow, wrong call order */
+#define GVC_ERR_UNSUPPORTED (-4)  /* dimension not supported by the kernels */
+
+typedef void* gvc_stream;         /* hipStream_t */
+
+int gvc_version(void);
+const char* gvc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GPT: prefill, KV-cached decode step, head, latent re-pass.
+ * Replaces layers/gpt.py:GPT.{init_gpt_for_inference,compute_embeddings(prefix store),forward
+ * (return_latent=True)} (gpt.py:197-218, 375-508, 572-592), layers/gpt_inference.py:
+ * GPT2InferenceModel.forward (:55-124) and the HF GPT2Model block stack it drives
+ * (gpt.py:42-84, gpt_inference.py:97-110).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_gpt gvc_gpt;
+
+typedef struct gvc_gpt_dims {
+    int32_t n_layer;      /* gpt_layers */
+    int32_t d_model;      /* gpt_n_model_channels; multiple of 256 */
+    int32_t n_head;       /* gpt_n_heads; head_dim = d_model / n_head must be 64 or 256 */
+    int32_t vocab;        /* gpt_num_audio_tokens (1026) */
+    int32_t max_mel_pos;  /* rows of mel_pos_embedding (608) */
+    int32_t max_text_pos; /* rows of text_pos_embedding (404) */
+    int32_t n_text;       /* gpt_number_text_tokens (258) */
+    int32_t max_seq;      /* KV-cache positions per slot (>= 1083, gpt.py:198) */
+    int32_t max_slots;    /* concurrent streams whose KV cache is resident */
+    int32_t max_rows;     /* capacity (rows) of one prefill / latent re-pass call, all slots together */
+} gvc_gpt_dims;
+
+int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out);
+int gvc_gpt_destroy(gvc_gpt* ctx);
+
+/* One-time repack of a tensor named as in the reference GPT state dict, e.g.
+ * "gpt.h.3.attn.c_attn.weight" (HF Conv1D [in,out] -> row-per-output layout), "mel_head.weight",
+ * "mel_embedding.weight", "final_norm.bias".  `src` is a device pointer with `numel` floats.
+ * Unknown names (text_head.*, attn.bias buffers, conditioning_perceiver.*) return GVC_OK and are
+ * ignored, mirroring load_state_dict(strict=False) at inference/model_init.py:22. */
+int gvc_gpt_bind_weight(gvc_gpt* ctx, const char* name, const float* src, int64_t numel, gvc_stream s);
+/* number of GPT tensors still unbound (0 = ready) */
+int gvc_gpt_missing_weights(gvc_gpt* ctx);
+
+/* Build the prefix embeddings of GPT.compute_embeddings (gpt.py:572-581):
+ * prefix[b] = [cond_latents[b] (n_cond rows) | text_embedding(<s> codes </s>) + text_pos[0..Tc+1]].
+ * codes: int32 [B,Tc] content codes; out: [B, n_cond+Tc+2, d]. */
+int gvc_gpt_prefix_embeddings(gvc_gpt* ctx, const float* cond_latents, int32_t n_cond,
+                              const int32_t* codes, int32_t B, int32_t Tc, int32_t start_text,
+                              int32_t stop_text, float* out, gvc_stream s);
+
+/* Prefill (gpt_inference.py:81-91): rows = [prefix_emb[b] (P rows) | mel_embedding[start_tok] +
+ * mel_pos[0]]; fills the KV cache of slots[b] (positions 0..P), sets its length to P+1 and its next
+ * mel position to 1; writes the last row's latent = final_norm(ln_f(h)) [B,d] and logits [B,vocab].
+ * logits_out / latent_out may be NULL: the results then stay in the context's staging buffers, which is
+ * where gvc_gpt_generate reads the first step's logits from. */
+int gvc_gpt_prefill(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
+                    int32_t start_tok, float* logits_out, float* latent_out, gvc_stream s);
+
+/* One KV-cached decode step for B streams (gpt_inference.py:92-112):
+ * x = mel_embedding[tok_in[b]] + mel_pos[pos(slot)], 30 blocks against the cache, double
+ * LayerNorm, mel_head.  Appends K/V, advances the slot's length and mel position. */
+int gvc_gpt_decode_step(gvc_gpt* ctx, const int32_t* slots, int32_t B, const int32_t* tok_in,
+                        float* logits_out, float* latent_out, gvc_stream s);
+
+/* Reset a slot (length 0, mel position 0) so that decode steps can also build a context from
+ * nothing (used by tests). */
+int gvc_gpt_reset_slots(gvc_gpt* ctx, const int32_t* slots, int32_t B, gvc_stream s);
+
+/* Teacher-forced latent re-pass, GPT.forward(..., cond_latents=, return_latent=True)
+ * (gpt.py:375-508, call site inference_utils.py:71-76): rows = [prefix_emb (P) | start, codes(n),
+ * stop x4]; out[b] = final_norm(ln_f(h)) of the first n mel rows -> [B,n,d].  Uses scratch slot
+ * `slots[b]` for K/V (its previous content is overwritten).  gen_codes: int32 [B,n]. */
+int gvc_gpt_latents(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
+                    const int32_t* gen_codes, int32_t n, int32_t start_tok, int32_t stop_tok,
+                    float* out, gvc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampling.  Replaces the per-step body of NewGenerationMixin.sample_stream
+ * (layers/stream_generator.py:834-874): RepetitionPenalty -> Temperature -> TopK -> TopP ->
+ * softmax -> draw, finished rows emit the pad token.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_sample_params {
+    float repetition_penalty;   /* 2.0 */
+    float temperature;          /* 0.85 */
+    float top_p;                /* 0.85; >= 1 disables */
+    int32_t top_k;              /* 15; <= 0 disables; 1 = greedy (argmax of penalised logits) */
+    int32_t eos_token;          /* stop_audio_token 1025 (also the pad) */
+    int32_t vocab;              /* 1026 */
+    uint64_t seed;              /* counter-based RNG key (torch.multinomial is not reproducible) */
+} gvc_sample_params;
+
+/* ids: int32 [B, ids_stride] row b holds the input_ids of the reference loop (fake prefix ids
+ * 1..1,1024 followed by the generated tokens); ids_len[b] = current length (updated +1);
+ * finished[b] in/out (1 once eos was emitted); step = RNG counter.  tok_out[b] receives the token. */
+int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride, int32_t* ids_len,
+               int32_t* finished, const gvc_sample_params* p, int32_t step, int32_t* tok_out,
+               gvc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused generation loop: prefill state -> n_steps x (sample, decode step) replayed from one
+ * captured hipGraph with all step state on the device (no host sync per token; the reference
+ * syncs at stream_generator.py:877).  Replaces GPT.generate / GPT.get_generator (gpt.py:594-621).
+ *
+ * Call after gvc_gpt_prefill(..., logits_out=NULL, latent_out=NULL, ...) on the same slots.  Per step i in [0,n_steps): samples token i from
+ * the current logits, stores it at tokens_out[b*tok_stride + i0 + i] and the latent that predicted
+ * it at latents_out[(b*lat_stride + i0 + i)*d], then runs the decode step that consumes it.
+ * ids / ids_len / finished as in gvc_sample (the caller initialises them from compute_embeddings).
+ * ------------------------------------------------------------------------------------------ */
+int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
+                     int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
+                     int32_t n_steps, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
+                     int32_t lat_stride, gvc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Perceiver resampler.  Replaces layers/perceiver_encoder.py:PerceiverResampler.forward (:265-276)
+ * as called by GPT.get_style_emb (gpt.py:351-373) with mask=None.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_perceiver gvc_perceiver;
+typedef struct gvc_perceiver_dims {
+    int32_t dim, depth, dim_context, num_latents, dim_head, heads, ff_mult;
+    int32_t max_batch, max_frames;
+} gvc_perceiver_dims;
+
+int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceiver** out);
+int gvc_perceiver_destroy(gvc_perceiver* ctx);
+/* names relative to the module: "latents", "proj_context.weight", "layers.0.0.to_q.weight",
+ * "layers.0.1.0.weight", "norm.gamma", ... */
+int gvc_perceiver_bind_weight(gvc_perceiver* ctx, const char* name, const float* src, int64_t numel,
+                              gvc_stream s);
+int gvc_perceiver_missing_weights(gvc_perceiver* ctx);
+/* x: [B,F,dim_context] -> out [B,num_latents,dim] */
+int gvc_perceiver_forward(gvc_perceiver* ctx, const float* x, int32_t B, int32_t F, float* out,
+                          gvc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Log-mel front end.  Replaces utils.py:TorchMelSpectrogram.forward (:150-162) as instantiated at
+ * trainers/hifigan_trainer.py:105-115 (n_fft 2048, hop 256, win 1024, 24 kHz, 0-8 kHz, 80 mels,
+ * slaney norm, htk scale, centre + reflect pad).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_mel gvc_mel;
+int gvc_mel_create(int32_t n_fft, int32_t hop, int32_t win, int32_t sample_rate, float f_min,
+                   float f_max, int32_t n_mels, const float* mel_norms_host, gvc_mel** out);
+int gvc_mel_destroy(gvc_mel* ctx);
+/* wav [B,T] -> out [B,n_mels,1+T/hop] (reference layout); if out_frames_major != NULL it also
+ * receives [B,1+T/hop,n_mels] (the layout the Perceiver consumes). */
+int gvc_mel_forward(gvc_mel* ctx, const float* wav, int32_t B, int32_t T, float* out,
+                    float* out_frames_major, gvc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Content tokenizer.  Replaces layers/dvae.py:DiscreteVAE.get_codebook_indices (:324-331) with
+ * the 1-D encoder of :252-291 and Quantize.forward (:87-93).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_dvae gvc_dvae;
+typedef struct gvc_dvae_dims {
+    int32_t channels, hidden_dim, num_layers, num_resnet_blocks, kernel_size, codebook_dim,
+        num_tokens;
+    int32_t max_batch, max_frames;
+} gvc_dvae_dims;
+int gvc_dvae_create(const gvc_dvae_dims* dims, gvc_dvae** out);
+int gvc_dvae_destroy(gvc_dvae* ctx);
+/* names relative to the module: "encoder.0.0.weight", "encoder.2.net.0.bias", "codebook.embed" */
+int gvc_dvae_bind_weight(gvc_dvae* ctx, const char* name, const float* src, int64_t numel, gvc_stream s);
+int gvc_dvae_missing_weights(gvc_dvae* ctx);
+/* feat [B,channels,T] (reference layout) -> codes int32 [B,Tc], Tc = T halved num_layers times
+ * (ceil); enc_out (optional, may be NULL) receives the encoder output [B,Tc,codebook_dim]. */
+int gvc_dvae_encode(gvc_dvae* ctx, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
+                    float* enc_out, gvc_stream s);
+/* standalone VQ: x [N,dim], embed [dim,n_embed] (reference layout) -> idx int32 [N] */
+int gvc_vq_argmin(const float* x, const float* embed, int32_t N, int32_t dim, int32_t n_embed,
+                  int32_t* idx, float* work /* N*n_embed floats */, gvc_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENVC_HIP_H */

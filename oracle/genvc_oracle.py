@@ -317,15 +317,17 @@ def process_logits(logits, ids, rep_penalty=2.0, temperature=0.85, top_k=15, top
 
 
 def sample_from_scores(scores, seed, step):
-    """softmax + inverse-CDF draw in vocabulary order: first i with cdf[i] >= u * cdf[-1]."""
-    probs = torch.softmax(scores, dim=-1)
+    """softmax + inverse-CDF draw in vocabulary order: with e = exp(s - max) (fp32) and a running
+    float64 mass, the token is the first surviving index whose mass reaches u * total."""
     out = torch.empty(scores.shape[0], dtype=torch.long)
     for b in range(scores.shape[0]):
-        cdf = torch.cumsum(probs[b].double(), 0)
-        u = rng_uniform(seed, step, b) * float(cdf[-1])
-        nz = (probs[b] > 0)
-        idx = int(torch.nonzero((cdf >= u) & nz)[0]) if u > 0 else int(torch.nonzero(nz)[0])
-        out[b] = idx
+        s = scores[b]
+        kept = torch.isfinite(s)
+        e = torch.where(kept, torch.exp(s - s[kept].max()), torch.zeros_like(s))
+        cdf = torch.cumsum(e.double(), 0)
+        target = float(np.float32(rng_uniform(seed, step, b))) * float(cdf[-1])
+        hit = torch.nonzero((cdf >= target) & kept)
+        out[b] = int(hit[0]) if len(hit) else int(torch.nonzero(kept)[-1])
     return out
 
 
