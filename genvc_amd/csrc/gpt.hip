@@ -1,6 +1,8 @@
 // GPT context of libgenvc_hip: weight binding/repack, KV cache, prefill, decode step, latent re-pass,
 // graph-replayed generation loop.  Reference seams: layers/gpt.py, layers/gpt_inference.py (see
 // include/genvc_hip.h for the line-level mapping).
+#include <stdlib.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -153,6 +155,7 @@ struct GptLayer {
 struct gvc_gpt {
     gvc_gpt_dims dm;
     int hd = 0, n_cu = 256;
+    int prefetch = 0;                 // experimental L2 warm-up of the next launch's weights (GVC_PREFETCH=1)
     float* wbase = nullptr;           // one allocation for all weights
     float *mel_emb, *mel_pos, *text_emb, *text_pos, *lnf_w, *lnf_b, *fn_w, *fn_b, *head_w, *head_b;
     std::vector<GptLayer> layers;
@@ -196,6 +199,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipGetDevice(&dev));
     GVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (getenv("GVC_PREFETCH")) c->prefetch = atoi(getenv("GVC_PREFETCH"));
 
     const size_t d = D.d_model, L = D.n_layer, V = D.vocab;
     const size_t per_layer = 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d;
@@ -322,26 +326,58 @@ extern "C" int gvc_gpt_missing_weights(gvc_gpt* c) {
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
+struct GemvGeom { int NI, ksplit, wpb, grid; };
+
+// launch geometry of a decode GEMV over Wt[N][K]: one wave per (row, 1024-input segment); about one
+// workgroup per CU, two when that would need more than 12 compute waves (+1 prefetcher wave each)
+static int gemv_geom(const gvc_gpt* c, int N, int K, GemvGeom* g) {
+    g->NI = (K < 1024 ? K : 1024) / 256;
+    GVC_REQUIRE(g->NI == 1 || g->NI == 4, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
+    g->ksplit = K / (g->NI * 256);
+    GVC_REQUIRE(g->ksplit * g->NI * 256 == K && g->ksplit <= 8, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
+    const int items = N * g->ksplit;
+    int wpb = cdiv(items, c->n_cu);
+    if (wpb > 12) wpb = cdiv(items, 2 * c->n_cu);
+    if (wpb < 4) wpb = 4;
+    wpb = cdiv(wpb, g->ksplit) * g->ksplit;
+    if (wpb > 15) wpb = 15 / g->ksplit * g->ksplit;
+    g->wpb = wpb;
+    g->grid = cdiv(items, wpb);
+    return GVC_OK;
+}
+
+static Prefetch prefetch_of(const gvc_gpt* c, const float* Wt, int N, int K) {
+    Prefetch p;
+    p.base = nullptr; p.chunk_bytes = 0; p.n_chunks = 0;
+    GemvGeom g;
+    if (gemv_geom(c, N, K, &g) == GVC_OK) {
+        p.base = (const char*)Wt;
+        p.chunk_bytes = g.wpb * g.NI * 256 * (int)sizeof(float);
+        p.n_chunks = g.grid;
+        // the last workgroup may own fewer rows: clamp so no byte beyond the matrix is touched
+        const long long total = (long long)N * K * (long long)sizeof(float);
+        while (p.n_chunks > 0 && (long long)p.n_chunks * p.chunk_bytes > total) --p.n_chunks;
+    }
+    return p;
+}
+
 template <int PRO, int EPI>
 static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
-    const int NI = (A.K < 1024 ? A.K : 1024) / 256;
-    GVC_REQUIRE(NI == 1 || NI == 4, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", A.K);
-    A.ksplit = A.K / (NI * 256);
-    GVC_REQUIRE(A.ksplit * NI * 256 == A.K, GVC_ERR_UNSUPPORTED, "gemv: K=%d not a multiple of %d", A.K, NI * 256);
-    const int items = A.N * A.ksplit;
-    int wpb = cdiv(items, c->n_cu);
-    if (wpb < 4) wpb = 4;
-    if (wpb > 16) wpb = 16;
-    wpb = cdiv(wpb, A.ksplit) * A.ksplit;
-    GVC_REQUIRE(wpb <= 16, GVC_ERR_UNSUPPORTED, "gemv: ksplit %d too large", A.ksplit);
-    A.wpb = wpb;
+    GemvGeom g;
+    int rc = gemv_geom(c, A.N, A.K, &g);
+    if (rc) return rc;
+    const int NI = g.NI;
+    A.ksplit = g.ksplit;
+    A.wpb = g.wpb;
     A.B = B;
     const int BT = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
-    const int grid = cdiv(items, wpb);
+    const int grid = g.grid;
+    const int wpb = g.wpb;
+    const int nthreads = (wpb + (A.pf.base ? 1 : 0)) * 64;
     const size_t lds = ((size_t)BT * A.K + (size_t)wpb * BT) * sizeof(float);
 #define GVC_GEMV_CASE(bt, ni)                                                    \
     if (BT == bt && NI == ni) {                                                  \
-        hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI>), dim3(grid), dim3(wpb * 64), lds, s, A); \
+        hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI>), dim3(grid), dim3(nthreads), lds, s, A); \
         GVC_LAUNCH_CHECK();                                                      \
         return GVC_OK;                                                           \
     }
@@ -394,12 +430,13 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
 
 static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s) {
     dim3 grid(chunks, c->dm.n_head, rows);
+    dim3 block(T.pf.base ? 320 : 256);
     if (c->hd == 256) {
-        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, dim3(256), 0, s, T);
-        else hipLaunchKernelGGL((k_attention<256, false>), grid, dim3(256), 0, s, T);
+        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);
     } else {
-        if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, dim3(256), 0, s, T);
-        else hipLaunchKernelGGL((k_attention<64, false>), grid, dim3(256), 0, s, T);
+        if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<64, false>), grid, block, 0, s, T);
     }
     GVC_LAUNCH_CHECK();
     return GVC_OK;
@@ -440,24 +477,31 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
 
         AttnArgs T = gpt_attn_args(c, l, slots);
         T.q = qb; T.T = 1; T.base_len = c->st.seq_len; T.out = pb;
+        if (c->prefetch) T.pf = prefetch_of(c, ly.proj_w, d, d);
         if ((rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.proj_w; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
+        if (c->prefetch) A.pf = prefetch_of(c, ly.fc_w, 4 * d, d);
         if ((rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
+        if (c->prefetch) A.pf = prefetch_of(c, ly.p2_w, d, 4 * d);
         if ((rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
+        if (c->prefetch)
+            A.pf = l + 1 < c->dm.n_layer ? prefetch_of(c, c->layers[l + 1].qkv_w, 3 * d, d)
+                                         : prefetch_of(c, c->head_w, c->dm.vocab, d);
         if ((rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
     }
     GemvArgs A = base_args(c, slots, row0);
     A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
     A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
     A.out = logits_out; A.latent_out = latent_out; A.advance = 1; A.step_ctr = step_ctr;
+    if (c->prefetch) A.pf = prefetch_of(c, c->layers[0].qkv_w, 3 * d, d);   // next step's first operand
     return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
 }
 

@@ -18,6 +18,13 @@ struct GptState {                // device-resident step state, one entry per sl
     int32_t* mel_pos;            // index into mel_pos_embedding of the next decode input
 };
 
+// see prefetch_wave() below
+struct Prefetch {
+    const char* base;    // null: nothing to prefetch
+    int chunk_bytes;     // bytes read by one workgroup of the next launch (contiguous)
+    int n_chunks;
+};
+
 enum Prologue { PRO_LN = 0, PRO_MERGE = 1, PRO_COPY = 2, PRO_LN2X = 3 };
 enum Epilogue { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
@@ -49,6 +56,7 @@ struct GemvArgs {
     GptState st;
     int advance;                                // EPI_LOGITS: 1 -> seq_len++, mel_pos++ per slot
     int32_t* step_ctr;                          // EPI_LOGITS: nullable, ++ once per launch (generation loop)
+    Prefetch pf;                                // next launch's weights (L2 warm-up by the extra wave)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -62,12 +70,36 @@ struct GemvArgs {
 // vmcnt retires in order, hence the small prologue loads are issued BEFORE the weight stream.
 // HBM-bound: N*K*4 algorithmic bytes per launch.  BT = streams per launch (padded), B live ones.
 // ---------------------------------------------------------------------------------------------
+// Warm the XCD-local L2 with the weights the NEXT kernel will stream.  Executed by one extra wave per
+// workgroup that returns right afterwards: its loads are fire-and-forget (s_endpgm waits for them), so
+// the compute waves' in-order vmcnt never sees them and the kernel overlaps its own latency chain with
+// the next operand's HBM transfer.  Chunk cb is what workgroup cb of the next launch reads; it is
+// fetched by a workgroup with the same index modulo 8 (observed XCD placement; affects speed only).
+__device__ __forceinline__ void prefetch_wave(const Prefetch& P, int lane, int block, int nblocks) {
+    const int r = block & 7;
+    const int nb_r = (nblocks - r + 7) >> 3;            // workgroups of this launch with residue r
+    const int i = block >> 3;
+    // hipcc does not track an asm load: the destination is a register kept live ("+v") up to our own
+    // wait, so it can never be re-used for an address while a load is still in flight
+    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int cb = r + 8 * i; cb < P.n_chunks; cb += 8 * nb_r) {
+        const char* p = P.base + (size_t)cb * P.chunk_bytes;
+        for (int off = lane * 16; off < P.chunk_bytes; off += 64 * 16)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p + off) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+}
+
 template <int BT, int NI, int PRO, int EPI>
 __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nwave = A.wpb;
+    const int nwave = A.wpb;                   // compute waves; wave == nwave is the prefetcher
+    if (wave >= nwave) {
+        if (A.pf.base) prefetch_wave(A.pf, lane, blockIdx.x, gridDim.x);
+        return;                                // a terminated wave no longer counts at s_barrier
+    }
     constexpr int KSEG = NI * 256;
     float* a_lds = smem;                       // [BT][K]
     float* red = smem + BT * A.K;              // [wpb][BT] cross-wave partial sums (ksplit > 1)
@@ -79,40 +111,21 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
     const float* wp = A.Wt + (size_t)(live ? row : 0) * A.K + seg * KSEG + lane * 4;
     float4 w[NI];
 
-    // LayerNorm (once or twice) of v in registers, result to LDS (and the latent output)
-    auto ln_store = [&](int b, float4 (&v)[NI]) {
-        const float inv_d = 1.0f / (float)A.d;
+    // ---- epilogue operands are requested first: nothing is loaded after the reduction ----
+    const bool fin = live && seg == 0 && lane < A.B;     // lane b finishes stream b
+    float e_bias = A.bias[live ? row : 0];
+    float e_res = 0.f;
+    int e_pos = 0;
+    if constexpr (EPI == EPI_RESID) {
+        if (fin) e_res = A.x[(size_t)(lane * A.x_stride + A.x_off) * A.d + row];
+    }
+    if constexpr (EPI == EPI_QKV) {
+        if (fin && row >= A.d) e_pos = A.st.seq_len[A.slots[lane]];
+    }
+
+    auto load_w = [&]() {
 #pragma unroll
-        for (int pass = 0; pass < (PRO == PRO_LN2X ? 2 : 1); ++pass) {
-            const float* gw = pass == 0 ? A.ln_w : A.ln2_w;
-            const float* gb = pass == 0 ? A.ln_b : A.ln2_b;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-            const float mean = wave_sum(s) * inv_d;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const float4 g = *reinterpret_cast<const float4*>(gw + i * 256 + lane * 4);
-                const float4 c = *reinterpret_cast<const float4*>(gb + i * 256 + lane * 4);
-                v[i].x = (v[i].x - mean) * rstd * g.x + c.x;
-                v[i].y = (v[i].y - mean) * rstd * g.y + c.y;
-                v[i].z = (v[i].z - mean) * rstd * g.z + c.z;
-                v[i].w = (v[i].w - mean) * rstd * g.w + c.w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            *reinterpret_cast<float4*>(a_lds + b * A.K + i * 256 + lane * 4) = v[i];
-            if (PRO == PRO_LN2X && blockIdx.x == 0)
-                *reinterpret_cast<float4*>(A.latent_out + (size_t)b * A.d + i * 256 + lane * 4) = v[i];
-        }
+        for (int i = 0; i < NI; ++i) w[i] = *reinterpret_cast<const float4*>(wp + i * 256);
     };
     // residual-stream row of stream b (layer 0 of a decode step builds it from the embeddings)
     auto load_x = [&](int b, float4 (&v)[NI]) {
@@ -133,19 +146,58 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
             for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
         }
     };
-    auto load_w = [&]() {
+    // one LayerNorm of v in registers
+    auto layer_norm = [&](float4 (&v)[NI], const float4 (&g)[NI], const float4 (&c)[NI]) {
+        const float inv_d = 1.0f / (float)A.d;
+        float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) w[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+        for (int i = 0; i < NI; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            v[i].x = (v[i].x - mean) * rstd * g[i].x + c[i].x;
+            v[i].y = (v[i].y - mean) * rstd * g[i].y + c[i].y;
+            v[i].z = (v[i].z - mean) * rstd * g[i].z + c[i].z;
+            v[i].w = (v[i].w - mean) * rstd * g[i].w + c[i].w;
+        }
+    };
+    auto load_gb = [&](const float* gw, const float* gb, float4 (&g)[NI], float4 (&c)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            g[i] = *reinterpret_cast<const float4*>(gw + i * 256 + lane * 4);
+            c[i] = *reinterpret_cast<const float4*>(gb + i * 256 + lane * 4);
+        }
+    };
+    auto ln_store = [&](int b, float4 (&v)[NI], const float4 (&g)[NI], const float4 (&c)[NI]) {
+        layer_norm(v, g, c);
+        if constexpr (PRO == PRO_LN2X) {
+            float4 g2[NI], c2[NI];
+            load_gb(A.ln2_w, A.ln2_b, g2, c2);
+            layer_norm(v, g2, c2);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            *reinterpret_cast<float4*>(a_lds + b * A.K + i * 256 + lane * 4) = v[i];
+            if (PRO == PRO_LN2X && blockIdx.x == 0)
+                *reinterpret_cast<float4*>(A.latent_out + (size_t)b * A.d + i * 256 + lane * 4) = v[i];
+        }
     };
 
     if constexpr (PRO == PRO_LN || PRO == PRO_LN2X) {
-        // one wave per stream (K == d == 256*NI); the first stream's row is requested before the weights
-        float4 v[NI];
+        // one wave per stream (K == d == 256*NI); row, gain and bias are requested before the weights
+        float4 v[NI], g[NI], c[NI];
         const bool mine = wave < A.B;
-        if (mine) load_x(wave, v);
+        if (mine) { load_x(wave, v); load_gb(A.ln_w, A.ln_b, g, c); }
         load_w();
-        if (mine) ln_store(wave, v);
-        for (int b = wave + nwave; b < A.B; b += nwave) { load_x(b, v); ln_store(b, v); }
+        if (mine) ln_store(wave, v, g, c);
+        for (int b = wave + nwave; b < A.B; b += nwave) { load_x(b, v); ln_store(b, v, g, c); }
         for (int b = A.B + wave; b < BT; b += nwave)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -153,13 +205,14 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
     } else if constexpr (PRO == PRO_COPY) {
         // a = in[b][0..K): every thread moves float4s; BT*K/4 of them, at most 8 per thread in flight
         const int total4 = BT * A.K / 4;
+        const int nthr = nwave * 64;
         constexpr int CU = 8;
         bool first = true;
-        for (int base = threadIdx.x; base < total4; base += blockDim.x * CU) {
+        for (int base = threadIdx.x; base < total4; base += nthr * CU) {
             float4 t[CU];
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
-                const int idx = base + u * blockDim.x;
+                const int idx = base + u * nthr;
                 const int b = (idx * 4) / A.K;
                 t[u] = (idx < total4 && b < A.B) ? *reinterpret_cast<const float4*>(A.in + (size_t)idx * 4)
                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,29 +220,32 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
             if (first) { load_w(); first = false; }
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
-                const int idx = base + u * blockDim.x;
+                const int idx = base + u * nthr;
                 if (idx < total4) *reinterpret_cast<float4*>(a_lds + (size_t)idx * 4) = t[u];
             }
         }
         if (first) load_w();
     } else {  // PRO_MERGE: combine the kAttnChunks partial softmax states of each head
-        load_w();
         const int pstride = A.head_dim + 4;   // (o[hd], m, l, pad): keeps float4 alignment
+        bool first = true;
         for (int b = wave; b < BT; b += nwave) {
             for (int k = lane * 4; k < A.K; k += 256) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                float mc[kAttnChunks], lc[kAttnChunks];
+                float4 oc[kAttnChunks];
                 if (b < A.B) {
                     const int h = k / A.head_dim;
                     const int j = k - h * A.head_dim;
                     const float* pp = A.in + ((size_t)(b * A.n_head + h) * kAttnChunks) * pstride;
-                    float mc[kAttnChunks], lc[kAttnChunks];
-                    float4 oc[kAttnChunks];
 #pragma unroll
                     for (int c = 0; c < kAttnChunks; ++c) {
                         mc[c] = pp[c * pstride + A.head_dim];
                         lc[c] = pp[c * pstride + A.head_dim + 1];
                         oc[c] = *reinterpret_cast<const float4*>(pp + c * pstride + j);
                     }
+                }
+                if (first) { load_w(); first = false; }     // partials requested, then the weight stream
+                if (b < A.B) {
                     float m = mc[0];
 #pragma unroll
                     for (int c = 1; c < kAttnChunks; ++c) m = fmaxf(m, mc[c]);
@@ -206,6 +262,7 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
                 *reinterpret_cast<float4*>(a_lds + b * A.K + k) = o;
             }
         }
+        if (first) load_w();
     }
     __syncthreads();
 
@@ -240,34 +297,31 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
     }
 
     // ---- epilogue: lane b finishes stream b ----
-    if (live && seg == 0) {
+    if (fin) {
         float val = 0.f;
 #pragma unroll
         for (int b = 0; b < BT; ++b)
             if (lane == b) val = acc[b];
-        if (lane < A.B) {
-            const int b = lane;
-            val += A.bias[row];
-            if constexpr (EPI == EPI_QKV) {
-                const int which = row / A.d;
-                const int c = row - which * A.d;
-                if (which == 0) {
-                    A.out[(size_t)b * A.d + c] = val;
-                } else {
-                    const int slot = A.slots[b];
-                    const int h = c / A.head_dim;
-                    const int j = c - h * A.head_dim;
-                    float* cache = which == 1 ? A.kcache : A.vcache;
-                    cache[(((size_t)slot * A.n_head + h) * A.max_seq + A.st.seq_len[slot]) * A.head_dim + j] = val;
-                }
-            } else if constexpr (EPI == EPI_RESID) {
-                float* xr = A.x + (size_t)(b * A.x_stride + A.x_off) * A.d;
-                xr[row] += val;
-            } else if constexpr (EPI == EPI_GELU) {
-                A.out[(size_t)b * A.N + row] = gelu_new(val);
+        const int b = lane;
+        val += e_bias;
+        if constexpr (EPI == EPI_QKV) {
+            const int which = row / A.d;
+            const int c = row - which * A.d;
+            if (which == 0) {
+                A.out[(size_t)b * A.d + c] = val;
             } else {
-                A.out[(size_t)b * A.N + row] = val;
+                const int slot = A.slots[b];
+                const int h = c / A.head_dim;
+                const int j = c - h * A.head_dim;
+                float* cache = which == 1 ? A.kcache : A.vcache;
+                cache[(((size_t)slot * A.n_head + h) * A.max_seq + e_pos) * A.head_dim + j] = val;
             }
+        } else if constexpr (EPI == EPI_RESID) {
+            A.x[(size_t)(b * A.x_stride + A.x_off) * A.d + row] = e_res + val;
+        } else if constexpr (EPI == EPI_GELU) {
+            A.out[(size_t)b * A.N + row] = gelu_new(val);
+        } else {
+            A.out[(size_t)b * A.N + row] = val;
         }
     }
     if constexpr (EPI == EPI_LOGITS) {
@@ -305,10 +359,17 @@ struct AttnArgs {
     float scale;
     float* out;                // DIRECT: [rows][out_stride] ; else partials [rows][heads][chunks][HD+4]
     int out_stride;
+    Prefetch pf;               // next launch's weights, fetched by the 5th wave (blockDim 320)
 };
 
 template <int HD, bool DIRECT>
-__global__ __launch_bounds__(256) void k_attention(const AttnArgs A) {
+__global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
+    if (threadIdx.x >= 256) {      // optional prefetcher wave, see prefetch_wave()
+        if (A.pf.base)
+            prefetch_wave(A.pf, threadIdx.x & 63, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                          gridDim.x * gridDim.y * gridDim.z);
+        return;
+    }
     constexpr int LPK = HD / 4;          // lanes per key
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
     constexpr int NG = 4 * KPW;          // softmax states per block
