@@ -85,7 +85,6 @@ def lib():
                                 "(there is no CPU fallback for the product path)")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            if not hasattr(L, name): continue  # TEMP until all kernels land
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,0 +1,307 @@
+// Content tokenizer: DiscreteVAE.get_codebook_indices (reference layers/dvae.py:324-331) = 1-D conv
+// encoder (:252-291, ResBlock :172-184) + nearest-codebook search (Quantize.forward :87-93).
+//
+// Activations are kept time-major [B][T + 2*pad][C] with zero rows at both ends, so a k-tap conv with
+// stride s is ONE fp32 MFMA GEMM whose A rows are overlapping windows of that buffer
+// (row t = &x[s*t][0], length k*C, lda = s*C) against weights repacked to [C_out][k*C_in]:
+// no im2col copy, bias/ReLU/skip fused in the GEMM epilogue.  Encoder weights are ~98 MB fp32 at the
+// reference size: weight-read bound at B=1.  VQ: one workgroup per frame, thread j owns code j and
+// evaluates the reference's expression (|x|^2 - 2 x.e_j) + |e_j|^2 in fp32; first index wins ties.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm.h"
+
+namespace gvc {
+
+// feat [B][C][T] (reference layout) -> xpad [B][T + 2*pad][C], rows [pad, pad+T)
+__global__ void k_to_time_major(const float* feat, float* xpad, int C, int T, int pad) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const float* src = feat + (size_t)b * C * T;
+    float* dst = xpad + (size_t)b * (T + 2 * pad) * C;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int c = c0 + r, t = t0 + threadIdx.x;
+        if (c < C && t < T) tile[r][threadIdx.x] = src[(size_t)c * T + t];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int t = t0 + r, c = c0 + threadIdx.x;
+        if (c < C && t < T) dst[(size_t)(t + pad) * C + c] = tile[threadIdx.x][r];
+    }
+}
+
+// zero the `pad` rows in front of and behind the T live rows of every batch element
+__global__ void k_zero_pad_rows(float* buf, int C, int T, int pad) {
+    const int b = blockIdx.y;
+    float* base = buf + (size_t)b * (T + 2 * pad) * C;
+    const int n = pad * C;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
+        if (i < n) base[i] = 0.f;
+        else base[(size_t)(T + pad) * C + (i - n)] = 0.f;
+    }
+}
+
+// Conv1d weight [Co][Ci][k] -> [Co][k*Ci] with column j*Ci + ci
+__global__ void k_repack_conv(const float* w, float* out, int Co, int Ci, int k) {
+    const size_t n = (size_t)Co * Ci * k;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % k);
+        const int ci = (int)((i / k) % Ci);
+        const int co = (int)(i / ((size_t)k * Ci));
+        out[((size_t)co * k + j) * Ci + ci] = w[i];
+    }
+}
+
+// ee[j] = sum_i embed[i][j]^2   (embed.pow(2).sum(0), dvae.py:88)
+__global__ void k_code_norms(const float* embed, float* ee, int dim, int n_embed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_embed) return;
+    float s = 0.f;
+    for (int i = 0; i < dim; ++i) { const float v = embed[(size_t)i * n_embed + j]; s += v * v; }
+    ee[j] = s;
+}
+
+// one workgroup per row of x [N][dim]; embed [dim][n_embed]; idx[row] = argmax_j -((xx - 2 x.e_j) + ee_j)
+__global__ __launch_bounds__(256) void k_vq_argmin(const float* x, const float* embed, const float* ee, int dim,
+                                                   int n_embed, int32_t* idx) {
+    extern __shared__ float xs[];              // [dim] + reduction scratch
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (size_t)row * dim;
+    float q = 0.f;
+    for (int i = tid; i < dim; i += 256) { const float v = xr[i]; xs[i] = v; q += v * v; }
+    const float xx = block4_sum(q, red);        // also orders the xs[] writes before the reads below
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < n_embed; j += 256) {
+        float dot = 0.f;
+        for (int i = 0; i < dim; ++i) dot = fmaf(xs[i], embed[(size_t)i * n_embed + j], dot);
+        const float dist = (xx - 2.0f * dot) + ee[j];
+        const float sc = -dist;
+        if (sc > best || (sc == best && j < bi)) { best = sc; bi = j; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
+        idx[row] = bi;
+    }
+}
+
+}  // namespace gvc
+
+using namespace gvc;
+
+struct ConvW { float* w = nullptr; float* b = nullptr; int Co = 0, Ci = 0, k = 0; };
+
+struct gvc_dvae {
+    gvc_dvae_dims dm;
+    int pad = 1, inner = 0;
+    std::vector<ConvW> down;            // strided conv + ReLU stages
+    std::vector<ConvW> res;             // 3 convs per ResBlock
+    ConvW last;                         // 1x1 to codebook_dim
+    float *embed = nullptr, *ee = nullptr;
+    std::map<std::string, int> bound;
+    int n_expected = 0;
+    float *buf[3] = {nullptr, nullptr, nullptr};   // padded time-major activations (ping-pong + residual temp)
+    float *enc = nullptr, *work = nullptr;
+    long long work_cap = 0;
+    std::vector<void*> allocs;
+};
+
+static int dalloc(gvc_dvae* c, float** p, size_t n) {
+    GVC_CHECK_HIP(hipMalloc((void**)p, n * sizeof(float)));
+    c->allocs.push_back(*p);
+    return GVC_OK;
+}
+
+extern "C" int gvc_dvae_create(const gvc_dvae_dims* dims, gvc_dvae** out) {
+    GVC_REQUIRE(dims && out, GVC_ERR_ARG, "gvc_dvae_create: null argument");
+    const gvc_dvae_dims& D = *dims;
+    GVC_REQUIRE(D.num_layers >= 1 && D.kernel_size % 2 == 1 && D.channels % 4 == 0 && D.hidden_dim % 4 == 0 &&
+                    D.codebook_dim % 4 == 0,
+                GVC_ERR_UNSUPPORTED, "dvae: need num_layers >= 1, odd kernel_size, channel counts %% 4 == 0");
+    auto* c = new gvc_dvae();
+    c->dm = D;
+    c->pad = (D.kernel_size - 1) / 2;
+    GVC_REQUIRE(c->pad >= 1 || D.num_resnet_blocks == 0, GVC_ERR_UNSUPPORTED, "dvae: kernel_size 1 with ResBlocks");
+    if (c->pad < 1) c->pad = 1;          // ResBlocks use k=3, pad=1
+    int rc = GVC_OK;
+    int cin = D.channels;
+    size_t maxc = cin;
+    for (int i = 0; i < D.num_layers && !rc; ++i) {
+        ConvW w; w.Co = D.hidden_dim << i; w.Ci = cin; w.k = D.kernel_size;
+        if (!(rc = dalloc(c, &w.w, (size_t)w.Co * w.Ci * w.k))) rc = dalloc(c, &w.b, w.Co);
+        c->down.push_back(w);
+        cin = w.Co;
+        if ((size_t)cin > maxc) maxc = cin;
+    }
+    c->inner = cin;
+    for (int i = 0; i < D.num_resnet_blocks && !rc; ++i)
+        for (int k : {3, 3, 1}) {
+            ConvW w; w.Co = cin; w.Ci = cin; w.k = k;
+            if (!(rc = dalloc(c, &w.w, (size_t)w.Co * w.Ci * w.k))) rc = dalloc(c, &w.b, w.Co);
+            c->res.push_back(w);
+        }
+    c->last.Co = D.codebook_dim; c->last.Ci = cin; c->last.k = 1;
+    if (!rc && !(rc = dalloc(c, &c->last.w, (size_t)D.codebook_dim * cin))) rc = dalloc(c, &c->last.b, D.codebook_dim);
+    if (!rc && !(rc = dalloc(c, &c->embed, (size_t)D.codebook_dim * D.num_tokens))) rc = dalloc(c, &c->ee, D.num_tokens);
+    c->n_expected = 2 * (D.num_layers + 3 * D.num_resnet_blocks + 1) + 1;
+    const size_t rows = (size_t)D.max_batch * (D.max_frames + 2 * c->pad);
+    for (int i = 0; i < 3 && !rc; ++i) rc = dalloc(c, &c->buf[i], rows * maxc);
+    if (!rc) rc = dalloc(c, &c->enc, (size_t)D.max_batch * D.max_frames * D.codebook_dim);
+    c->work_cap = 4ll << 20;
+    if (!rc) rc = dalloc(c, &c->work, (size_t)c->work_cap);
+    if (rc) { gvc_dvae_destroy(c); return rc; }
+    *out = c;
+    return GVC_OK;
+}
+
+extern "C" int gvc_dvae_destroy(gvc_dvae* c) {
+    if (!c) return GVC_OK;
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+    return GVC_OK;
+}
+
+static int bind_conv(ConvW& w, bool is_bias, const float* src, int64_t numel, const char* name, hipStream_t s) {
+    if (is_bias) {
+        GVC_REQUIRE(numel == w.Co, GVC_ERR_ARG, "%s: expected %d elements, got %lld", name, w.Co, (long long)numel);
+        GVC_CHECK_HIP(hipMemcpyAsync(w.b, src, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return GVC_OK;
+    }
+    GVC_REQUIRE(numel == (int64_t)w.Co * w.Ci * w.k, GVC_ERR_ARG, "%s: expected %lld elements, got %lld", name,
+                (long long)w.Co * w.Ci * w.k, (long long)numel);
+    hipLaunchKernelGGL(k_repack_conv, dim3(1024), dim3(256), 0, s, src, w.w, w.Co, w.Ci, w.k);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_dvae_bind_weight(gvc_dvae* c, const char* name, const float* src, int64_t numel, gvc_stream sv) {
+    GVC_REQUIRE(c && name && src, GVC_ERR_ARG, "gvc_dvae_bind_weight: null argument");
+    hipStream_t s = (hipStream_t)sv;
+    std::string n(name);
+    int rc = GVC_OK;
+    bool known = true;
+    if (n == "codebook.embed") {
+        GVC_REQUIRE(numel == (int64_t)c->dm.codebook_dim * c->dm.num_tokens, GVC_ERR_ARG, "%s: wrong size", name);
+        GVC_CHECK_HIP(hipMemcpyAsync(c->embed, src, numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_code_norms, dim3(cdiv(c->dm.num_tokens, 256)), dim3(256), 0, s, c->embed, c->ee,
+                           c->dm.codebook_dim, c->dm.num_tokens);
+        GVC_LAUNCH_CHECK();
+    } else if (n.rfind("encoder.", 0) == 0) {
+        const size_t dot = n.find('.', 8);
+        GVC_REQUIRE(dot != std::string::npos, GVC_ERR_ARG, "malformed weight name %s", name);
+        const int idx = atoi(n.substr(8, dot - 8).c_str());
+        const std::string rest = n.substr(dot + 1);
+        const int nd = c->dm.num_layers, nr = c->dm.num_resnet_blocks;
+        const bool is_bias = rest.size() >= 4 && rest.compare(rest.size() - 4, 4, "bias") == 0;
+        if (idx < nd) {
+            if (rest == "0.weight" || rest == "0.bias") rc = bind_conv(c->down[idx], is_bias, src, numel, name, s);
+            else known = false;
+        } else if (idx < nd + nr) {
+            int j = -1;
+            if (rest.rfind("net.0.", 0) == 0) j = 0;
+            else if (rest.rfind("net.2.", 0) == 0) j = 1;
+            else if (rest.rfind("net.4.", 0) == 0) j = 2;
+            if (j >= 0) rc = bind_conv(c->res[3 * (idx - nd) + j], is_bias, src, numel, name, s);
+            else known = false;
+        } else if (idx == nd + nr && (rest == "weight" || rest == "bias")) {
+            rc = bind_conv(c->last, is_bias, src, numel, name, s);
+        } else {
+            known = false;
+        }
+    } else {
+        known = false;      // decoder.*, codebook.cluster_size, ... (training state)
+    }
+    if (rc == GVC_OK && known) c->bound[n] = 1;
+    return rc;
+}
+
+extern "C" int gvc_dvae_missing_weights(gvc_dvae* c) { return c ? c->n_expected - (int)c->bound.size() : -1; }
+
+// out rows [pad, pad+To) of `dst` (time-major, padded) = act(conv(src)) (+ skip)
+static int conv_gemm(gvc_dvae* c, const ConvW& w, const float* src, int Tin, int stride, float* dst, int To, int B,
+                     int act, const float* skip, bool dst_padded, hipStream_t s) {
+    const int pad = c->pad;
+    const int cpad = (w.k - 1) / 2;                 // this conv's own padding (<= pad)
+    GemmArgs G;
+    memset(&G, 0, sizeof(G));
+    G.A = src + (size_t)(pad - cpad) * w.Ci;        // window of row t starts at padded row stride*t + (pad - cpad)
+    G.lda = stride * w.Ci;
+    G.a_batch_stride = (long long)(Tin + 2 * pad) * w.Ci;
+    G.Wt = w.w; G.ldw = w.k * w.Ci;
+    G.M = To; G.N = w.Co; G.K = w.k * w.Ci;
+    G.ldc = w.Co;
+    if (dst_padded) { G.C = dst + (size_t)pad * w.Co; G.c_batch_stride = (long long)(To + 2 * pad) * w.Co; }
+    else { G.C = dst; G.c_batch_stride = (long long)To * w.Co; }
+    G.work = c->work;
+    G.e.bias = w.b; G.e.act = act;
+    if (skip) { G.e.resid = skip + (size_t)pad * w.Co; G.e.ldr = w.Co; G.e.resid_batch_stride = (long long)(To + 2 * pad) * w.Co; }
+    return launch_gemm_cap(G, B, c->work_cap, s);
+}
+
+static int zero_pads(gvc_dvae* c, float* buf, int C, int T, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_pad_rows, dim3(cdiv(2 * c->pad * C, 256), B), dim3(256), 0, s, buf, C, T, c->pad);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_dvae_encode(gvc_dvae* c, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
+                               float* enc_out, gvc_stream sv) {
+    GVC_REQUIRE(c && feat && codes_out, GVC_ERR_ARG, "gvc_dvae_encode: null argument");
+    GVC_REQUIRE(gvc_dvae_missing_weights(c) == 0, GVC_ERR_STATE, "%d DVAE weight tensors are not bound",
+                gvc_dvae_missing_weights(c));
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_batch && T >= 1 && T <= c->dm.max_frames, GVC_ERR_ARG,
+                "dvae: B=%d T=%d outside capacity (%d, %d)", B, T, c->dm.max_batch, c->dm.max_frames);
+    hipStream_t s = (hipStream_t)sv;
+    const int pad = c->pad;
+    int rc;
+    float *cur = c->buf[0], *nxt = c->buf[1], *tmp = c->buf[2];
+    int C = c->dm.channels, Tc = T;
+    hipLaunchKernelGGL(k_to_time_major, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(32, 8), 0, s, feat, cur, C, T, pad);
+    GVC_LAUNCH_CHECK();
+    if ((rc = zero_pads(c, cur, C, Tc, B, s))) return rc;
+    for (const ConvW& w : c->down) {                  // Conv1d(k, stride 2, pad (k-1)/2) + ReLU
+        const int To = (Tc + 2 * ((w.k - 1) / 2) - w.k) / 2 + 1;
+        if ((rc = conv_gemm(c, w, cur, Tc, 2, nxt, To, B, ACT_RELU, nullptr, true, s))) return rc;
+        if ((rc = zero_pads(c, nxt, w.Co, To, B, s))) return rc;
+        std::swap(cur, nxt);
+        C = w.Co; Tc = To;
+    }
+    for (size_t r = 0; r + 2 < c->res.size(); r += 3) {   // ResBlock: conv3-ReLU-conv3-ReLU-conv1 + skip
+        if ((rc = conv_gemm(c, c->res[r], cur, Tc, 1, nxt, Tc, B, ACT_RELU, nullptr, true, s))) return rc;
+        if ((rc = zero_pads(c, nxt, C, Tc, B, s))) return rc;
+        if ((rc = conv_gemm(c, c->res[r + 1], nxt, Tc, 1, tmp, Tc, B, ACT_RELU, nullptr, true, s))) return rc;
+        // 1x1 conv + skip, written over the block input (each element is read and written by one lane)
+        if ((rc = conv_gemm(c, c->res[r + 2], tmp, Tc, 1, cur, Tc, B, ACT_NONE, cur, true, s))) return rc;
+    }
+    float* enc = enc_out ? enc_out : c->enc;
+    if ((rc = conv_gemm(c, c->last, cur, Tc, 1, enc, Tc, B, ACT_NONE, nullptr, false, s))) return rc;
+    const int dim = c->dm.codebook_dim;
+    hipLaunchKernelGGL(k_vq_argmin, dim3(B * Tc), dim3(256), dim * sizeof(float), s, enc, c->embed, c->ee, dim,
+                       c->dm.num_tokens, codes_out);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+extern "C" int gvc_vq_argmin(const float* x, const float* embed, int32_t N, int32_t dim, int32_t n_embed, int32_t* idx,
+                             float* work, gvc_stream sv) {
+    GVC_REQUIRE(x && embed && idx && work && N >= 1, GVC_ERR_ARG, "gvc_vq_argmin: bad argument");
+    hipStream_t s = (hipStream_t)sv;
+    hipLaunchKernelGGL(k_code_norms, dim3(cdiv(n_embed, 256)), dim3(256), 0, s, embed, work, dim, n_embed);
+    GVC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_vq_argmin, dim3(N), dim3(256), dim * sizeof(float), s, x, embed, work, dim, n_embed, idx);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}

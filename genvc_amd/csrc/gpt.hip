@@ -429,17 +429,7 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
 }
 
 static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s) {
-    dim3 grid(chunks, c->dm.n_head, rows);
-    dim3 block(T.pf.base ? 320 : 256);
-    if (c->hd == 256) {
-        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
-        else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);
-    } else {
-        if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, block, 0, s, T);
-        else hipLaunchKernelGGL((k_attention<64, false>), grid, block, 0, s, T);
-    }
-    GVC_LAUNCH_CHECK();
-    return GVC_OK;
+    return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s);
 }
 
 static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {

@@ -81,7 +81,8 @@ __device__ __forceinline__ void prefetch_wave(const Prefetch& P, int lane, int b
     const int i = block >> 3;
     // hipcc does not track an asm load: the destination is a register kept live ("+v") up to our own
     // wait, so it can never be re-used for an address while a load is still in flight
-    float4 sink = make_float4(0.f, 0.f, 0.f, 0.f);
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t sink = {0.f, 0.f, 0.f, 0.f};
     for (int cb = r + 8 * i; cb < P.n_chunks; cb += 8 * nb_r) {
         const char* p = P.base + (size_t)cb * P.chunk_bytes;
         for (int off = lane * 16; off < P.chunk_bytes; off += 64 * 16)
@@ -457,6 +458,25 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
             if (j == 0) { pp[HD] = M; pp[HD + 1] = L; }
         }
     }
+}
+
+// host launcher shared by the GPT and Perceiver contexts
+static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& T, int chunks, int rows, bool direct,
+                                      hipStream_t s) {
+    dim3 grid(chunks, n_head, rows);
+    dim3 block(T.pf.base ? 320 : 256);
+    if (head_dim == 256) {
+        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);
+    } else if (head_dim == 64) {
+        if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<64, false>), grid, block, 0, s, T);
+    } else {
+        set_error("attention: head_dim %d unsupported (64 or 256)", head_dim);
+        return GVC_ERR_UNSUPPORTED;
+    }
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -115,3 +115,137 @@ class GptEngine:
                                      ptr(_i32(finished)), C.byref(params), i0, n_steps, ptr(_i32(tokens_out)),
                                      tokens_out.shape[1], ptr(latents_out),
                                      latents_out.shape[1] if latents_out is not None else 0, stream()), "generate")
+
+
+class PerceiverEngine:
+    """PerceiverResampler.forward (reference layers/perceiver_encoder.py:265-276)."""
+
+    def __init__(self, dim, depth=2, dim_context=None, num_latents=32, dim_head=64, heads=8, ff_mult=4,
+                 max_batch=8, max_frames=2816):
+        dim_context = dim if dim_context is None else dim_context
+        self.dim, self.num_latents, self.dim_context = dim, num_latents, dim_context
+        cd = _lib.PerceiverDims(dim, depth, dim_context, num_latents, dim_head, heads, ff_mult, max_batch, max_frames)
+        self._h = C.c_void_p()
+        check(lib().gvc_perceiver_create(C.byref(cd), C.byref(self._h)), "gvc_perceiver_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_perceiver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights, prefix=""):
+        for name, t in weights.items():
+            if not name.startswith(prefix) or not torch.is_tensor(t):
+                continue
+            t = _f32(t.detach().to(torch.float32).contiguous())
+            check(lib().gvc_perceiver_bind_weight(self._h, name[len(prefix):].encode(), ptr(t), t.numel(), stream()),
+                  f"bind {name}")
+        torch.cuda.current_stream().synchronize()
+        missing = lib().gvc_perceiver_missing_weights(self._h)
+        if missing:
+            raise _lib.GenvcHipError(f"{missing} Perceiver weight tensors missing after bind")
+
+    def forward(self, x):
+        """x [B,F,dim_context] -> [B,num_latents,dim]"""
+        B, F, _ = x.shape
+        out = torch.empty(B, self.num_latents, self.dim, device=x.device, dtype=torch.float32)
+        check(lib().gvc_perceiver_forward(self._h, ptr(_f32(x)), B, F, ptr(out), stream()), "perceiver_forward")
+        return out
+
+
+class MelEngine:
+    """TorchMelSpectrogram.forward (reference utils.py:150-162)."""
+
+    def __init__(self, mel_norms, n_fft=2048, hop=256, win=1024, sample_rate=24000, f_min=0.0, f_max=8000.0, n_mels=80):
+        import numpy as np
+        norms = np.ascontiguousarray(np.asarray(mel_norms, dtype=np.float32))
+        assert norms.shape == (n_mels,)
+        self.hop, self.n_mels = hop, n_mels
+        self._h = C.c_void_p()
+        check(lib().gvc_mel_create(n_fft, hop, win, sample_rate, f_min, f_max, n_mels,
+                                   norms.ctypes.data_as(_lib.c_f32p), C.byref(self._h)), "gvc_mel_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_mel_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, wav, frames_major=False):
+        """wav [B,T] -> [B,n_mels,1+T//hop]  (and [B,1+T//hop,n_mels] when frames_major)"""
+        B, T = wav.shape
+        nf = 1 + T // self.hop
+        out = torch.empty(B, self.n_mels, nf, device=wav.device, dtype=torch.float32)
+        fm = torch.empty(B, nf, self.n_mels, device=wav.device, dtype=torch.float32) if frames_major else None
+        check(lib().gvc_mel_forward(self._h, ptr(_f32(wav)), B, T, ptr(out), ptr(fm), stream()), "mel_forward")
+        return (out, fm) if frames_major else out
+
+
+class DvaeEngine:
+    """DiscreteVAE.get_codebook_indices (reference layers/dvae.py:324-331)."""
+
+    def __init__(self, cfg, max_batch=8, max_frames=1504):
+        self.cfg = dict(cfg)
+        cd = _lib.DvaeDims(cfg["num_channels"], cfg["hidden_dim"], cfg["num_layers"], cfg["num_resnet_blocks"],
+                           cfg["kernel_size"], cfg["codebook_dim"], cfg["num_tokens"], max_batch, max_frames)
+        self._h = C.c_void_p()
+        check(lib().gvc_dvae_create(C.byref(cd), C.byref(self._h)), "gvc_dvae_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_dvae_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights, prefix=""):
+        for name, t in weights.items():
+            if not name.startswith(prefix) or not torch.is_tensor(t) or not t.is_floating_point():
+                continue
+            t = _f32(t.detach().to(torch.float32).contiguous())
+            check(lib().gvc_dvae_bind_weight(self._h, name[len(prefix):].encode(), ptr(t), t.numel(), stream()),
+                  f"bind {name}")
+        torch.cuda.current_stream().synchronize()
+        missing = lib().gvc_dvae_missing_weights(self._h)
+        if missing:
+            raise _lib.GenvcHipError(f"{missing} DVAE weight tensors missing after bind")
+
+    def out_frames(self, T):
+        k = self.cfg["kernel_size"]
+        for _ in range(self.cfg["num_layers"]):
+            T = (T + 2 * ((k - 1) // 2) - k) // 2 + 1
+        return T
+
+    def encode(self, feat, return_enc=False):
+        """feat [B,C,T] -> int32 codes [B,Tc] (and the encoder output [B,Tc,codebook_dim])"""
+        B, _, T = feat.shape
+        Tc = self.out_frames(T)
+        codes = torch.empty(B, Tc, device=feat.device, dtype=torch.int32)
+        enc = torch.empty(B, Tc, self.cfg["codebook_dim"], device=feat.device, dtype=torch.float32) if return_enc else None
+        check(lib().gvc_dvae_encode(self._h, ptr(_f32(feat)), B, T, ptr(codes), ptr(enc), stream()), "dvae_encode")
+        return (codes, enc) if return_enc else codes
+
+
+def vq_argmin(x, embed):
+    """x [N,dim], embed [dim,n_embed] -> int32 [N] (Quantize.forward, reference layers/dvae.py:87-90)."""
+    N, dim = x.shape
+    idx = torch.empty(N, device=x.device, dtype=torch.int32)
+    work = torch.empty(N * embed.shape[1], device=x.device, dtype=torch.float32)
+    check(lib().gvc_vq_argmin(ptr(_f32(x)), ptr(_f32(embed)), N, dim, embed.shape[1], ptr(idx), ptr(work), stream()),
+          "vq_argmin")
+    return idx

@@ -1,0 +1,78 @@
+"""GPU parity of the front-end kernels: mel, Perceiver, content DVAE + VQ (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from genvc_amd import config as gcfg
+from genvc_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_mel_matches_oracle_within_1e4():
+    from genvc_amd.engine import MelEngine
+    from oracle import genvc_oracle as O
+    norms = np.load("genvc_amd/assets/mel_stats.npy")
+    eng = MelEngine(norms)
+    for T, frames in ((72000, 282), (144000, 563), (96000, 376), (98835, 387), (8000, 32)):
+        wav = synth.synth_audio(21, f"ref{T}", T)
+        wav = torch.cat([wav, synth.synth_audio(22, f"ref{T}", T, amplitude=0.5)], 0)
+        got, fm = eng.forward(wav.to(DEV), frames_major=True)
+        assert got.shape == (2, 80, frames)
+        ref32 = O.mel_spectrogram(wav, torch.from_numpy(norms))
+        ref64 = O.mel_spectrogram_dft64(wav.numpy(), norms)
+        np.testing.assert_allclose(got.cpu().numpy(), ref64, atol=1e-4)      # north_star: mel within 1e-4
+        np.testing.assert_allclose(got.cpu().numpy(), ref32.numpy(), atol=1e-4)
+        assert torch.equal(fm.transpose(1, 2), got)
+
+
+def test_perceiver_matches_reference(gold):
+    from genvc_amd.engine import PerceiverEngine
+    g = gold("perceiver")
+    seed = int(g["seed"])
+    for tag, margs, wseed in (("tiny", gcfg.TINY_MODEL_ARGS, 3), ("full", gcfg.DEFAULT_MODEL_ARGS, 1)):
+        d = margs["gpt_n_model_channels"]
+        w = synth.make_weights(wseed, synth.perceiver_weight_spec(d, prefix="conditioning_perceiver."), device=DEV)
+        eng = PerceiverEngine(dim=d, depth=4, dim_context=80, num_latents=32, dim_head=64, heads=8, ff_mult=4,
+                              max_batch=2, max_frames=600)
+        eng.bind(w, prefix="conditioning_perceiver.")
+        for B, Fr in ((1, 282), (2, 563)):
+            mel = synth.uniform(seed, f"mel_{B}_{Fr}", (B, 80, Fr), 1.0).to(DEV)
+            y = eng.forward(mel.permute(0, 2, 1).contiguous())          # [B,32,d]
+            np.testing.assert_allclose(y.transpose(1, 2).cpu().numpy(), g[f"{tag}_{B}_{Fr}"], atol=5e-5)
+        eng.close()
+
+
+def test_dvae_codes_match_reference(gold):
+    from genvc_amd.engine import DvaeEngine, vq_argmin
+    g = gold("dvae")
+    seed = int(g["seed"])
+    n_safe = n_all = 0
+    for tag, c in (("tiny", gcfg.TINY_CONTENT_DVAE), ("full", gcfg.DEFAULT_CONTENT_DVAE)):
+        w = synth.make_weights(seed, synth.dvae_weight_spec(c), device=DEV)
+        eng = DvaeEngine(c, max_batch=2, max_frames=304)
+        eng.bind(w)
+        for B, T in ((1, 49), (2, 299), (1, 199), (1, 16)):
+            feat = synth.uniform(seed, f"feat_{B}_{T}", (B, c["num_channels"], T), 1.0).to(DEV)
+            codes, enc = eng.encode(feat, return_enc=True)
+            ref = g[f"{tag}_codes_{B}_{T}"]
+            assert codes.shape == ref.shape
+            np.testing.assert_allclose(enc[:, :, :16].cpu().numpy(), g[f"{tag}_enc_{B}_{T}"], atol=2e-5)
+            # bit-exact wherever the reference's own decision margin exceeds fp32 reassociation noise
+            safe = g[f"{tag}_margin_{B}_{T}"] > 1e-4
+            n_safe += int(safe.sum()); n_all += safe.size
+            assert np.array_equal(codes.cpu().numpy()[safe], ref[safe])
+            # standalone VQ entry point on the same encoder output
+            idx = vq_argmin(enc.reshape(-1, enc.shape[-1]).contiguous(), w["codebook.embed"])
+            assert torch.equal(idx.view_as(codes), codes)
+        eng.close()
+    assert n_safe > 0.97 * n_all          # the margin screen excludes only a handful of frames
+
+
+def test_vq_first_index_wins_ties():
+    from genvc_amd.engine import vq_argmin
+    embed = synth.uniform(3, "e", (64, 32), 1.0).to(DEV)
+    embed[:, 7] = embed[:, 20]                       # duplicate code: the lower index must win
+    x = embed[:, [20, 5, 7]].t().contiguous()
+    assert vq_argmin(x, embed).cpu().tolist() == [7, 5, 7]
