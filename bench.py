@@ -1,0 +1,260 @@
+"""Headline benchmark of the GenVC codec-token generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU.
+A "step" = one synthetic utterance (10 s source @16 kHz, 3 s reference @24 kHz) pushed through the hot
+path exactly as inference_utils.synthesize_utt_streaming orders it:
+    reference wav -> log-mel -> Perceiver -> 32 conditioning latents                     (once)
+    per 1 s chunk: content features -> DVAE encoder + VQ -> prefix embeddings -> prefill (48 rows)
+                   -> 24 x (sample, KV-cached decode step) in groups of 8 tokens (the vocoder cadence)
+All inputs are resident in HBM before the clock starts.  Outside the timed path, and said so in `config`:
+ContentVec (third-party fairseq boundary, SURVEY 8a row 4: its 256-d features are the synthetic input) and
+the HiFi-GAN vocoder ("next").  Synthetic weights rarely emit EOS, so the token budget is
+fixed: round(1 s * 23.4375) = 23 tokens + the EOS step = 24 decode steps per chunk.
+N > 1: one process per GPU, utterances sharded by rank, no collective on the data path; the generated
+token ids are all-gathered (RCCL) inside the timed region.  value = utterances/s of the whole job.
+"""
+import argparse
+import json
+import os
+import platform
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from genvc_amd import config as gcfg          # noqa: E402
+from genvc_amd import synth                   # noqa: E402
+
+SRC_SECONDS, REF_SECONDS, CHUNK_SECONDS = 10.0, 3.0, 1.0
+STEPS_PER_CHUNK = 24                          # 23 tokens + EOS step
+GROUP = 8                                     # stream_chunk_size of the reference harness
+KERNEL_NAMES = ["c_attn_gemv(ln1+qkv)", "attention(split-key)", "attn_c_proj_gemv(merge+resid)",
+                "mlp_c_fc_gemv(ln2+gelu)", "mlp_c_proj_gemv(resid)", "head_gemv(2xln+mel_head)"]
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def kernel_bytes(dims, which, S):
+    """algorithmic bytes of one launch of a decode-step kernel class at B=1"""
+    d, V, H = dims["d_model"], dims["num_audio_tokens"], dims["n_head"]
+    f = 4
+    if which == 0:
+        return (3 * d * d + 3 * d + 2 * d + d + 3 * d) * f
+    if which == 1:
+        return (2 * S * d + d + 8 * H * (d // H + 4)) * f
+    if which == 2:
+        return (d * d + d + 8 * H * (d // H + 4) + 2 * d) * f
+    if which == 3:
+        return (4 * d * d + 4 * d + 2 * d + d + 4 * d) * f
+    if which == 4:
+        return (4 * d * d + d + 4 * d + 2 * d) * f
+    return (V * d + V + 4 * d + d + V + d) * f
+
+
+class Workload:
+    def __init__(self, device, rank):
+        from genvc_amd.inference.model_init import model_init_synthetic
+        self.dev = device
+        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=8)
+        m = self.model
+        self.dims = m.gpt.dims()
+        self.eng = m.gpt.engine
+        self.n_chunks = int(SRC_SECONDS / CHUNK_SECONDS)
+        from genvc_amd.layers.content_processor import contentvec_frames
+        self.t50 = contentvec_frames(int(CHUNK_SECONDS * 16000))                       # 49
+        # resident inputs: 4 distinct utterances per rank, cycled
+        self.ref = [synth.synth_audio(100 + rank * 16 + u, "ref", int(REF_SECONDS * 24000)).to(device) for u in range(4)]
+        self.feat = [synth.uniform(200 + rank * 16 + u, "content_feat", (self.n_chunks, 256, self.t50), 1.0, device=device)
+                     for u in range(4)]
+        from genvc_amd.engine import sample_params
+        self.sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=1), self.dims["num_audio_tokens"], -1, 0)
+        self.slots = torch.zeros(1, device=device, dtype=torch.int32)
+        n_tok = self.n_chunks * STEPS_PER_CHUNK
+        self.toks = torch.zeros(1, n_tok, device=device, dtype=torch.int32)
+        self.lats = torch.zeros(1, n_tok, self.dims["d_model"], device=device)
+        self.Tc = m.content_dvae._engine.out_frames(self.t50)                          # 13
+        self.P = 32 + self.Tc + 2
+        self.ids = torch.ones(1, self.P + 1 + STEPS_PER_CHUNK + 8, device=device, dtype=torch.int32)
+        self.ids_len = torch.zeros(1, device=device, dtype=torch.int32)
+        self.fin = torch.zeros(1, device=device, dtype=torch.int32)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def utterance(self, u, record=False):
+        m, eng = self.model, self.eng
+        if record:
+            self.ev[0].record()
+        cond = m.get_gpt_cond_latents(self.ref[u % 4], 24000)                          # mel + Perceiver
+        feat = self.feat[u % 4]
+        for c in range(self.n_chunks):
+            codes = m.content_dvae._engine.encode(feat[c:c + 1])                       # DVAE + VQ (int32 [1,13])
+            prefix = eng.prefix_embeddings(cond, codes)
+            self.ids.fill_(1)
+            self.ids[:, self.P] = self.dims["start_audio_token"]
+            self.ids_len.fill_(self.P + 1)
+            self.fin.zero_()
+            eng.prefill(self.slots, prefix, want_outputs=False)
+            base = c * STEPS_PER_CHUNK
+            tok_view = self.toks[:, base:base + STEPS_PER_CHUNK]
+            lat_view = self.lats[:, base:base + STEPS_PER_CHUNK]
+            for g in range(0, STEPS_PER_CHUNK, GROUP):
+                eng.generate(self.slots, self.ids, self.ids_len, self.fin, self.sp, g, GROUP, tok_view, lat_view)
+                if record and c == 0 and g == 0:
+                    self.ev[1].record()                                                # first 8-token group done
+        if record:
+            self.ev[2].record()
+        return self.toks
+
+
+def cpu_baseline(wl, budget_s=20.0):
+    """The oracle (port) on the host cores, one 1 s chunk at a time (DVAE+VQ, prefix, prefill, 24 steps)."""
+    from oracle import genvc_oracle as O
+    m = wl.model
+    w = {k[len("gpt."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("gpt.")}
+    wd = {k[len("content_dvae."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("content_dvae.")}
+    dims = wl.dims
+    norms = m.torch_mel_spectrogram_style_encoder.mel_norms
+    greedy = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
+    # batch-1 GEMVs scale badly past a few dozen threads: give the CPU its best thread count
+    cond0 = torch.zeros(1, 32, dims["d_model"])
+    codes0 = torch.zeros(1, 13, dtype=torch.long)
+    best = None
+    for nt in (8, 16, 32, 64, os.cpu_count() or 8):
+        if nt > (os.cpu_count() or 8):
+            continue
+        torch.set_num_threads(nt)
+        t0 = time.time()
+        O.generate(w, dims, cond0, codes0, greedy, max_new=3, stop_on_eos=False)
+        t = time.time() - t0
+        if best is None or t < best[0]:
+            best = (t, nt)
+    cores = best[1]
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    cond = O.get_gpt_cond_latents(w, wl.ref[0].cpu(), norms)
+    t_ref = time.time() - t0
+    feat = wl.feat[0].cpu()
+
+    def chunk(c):
+        codes = O.dvae_get_codebook_indices(wd, feat[c:c + 1])
+        O.generate(w, dims, cond, codes, greedy, max_new=STEPS_PER_CHUNK, stop_on_eos=False)
+
+    chunk(0)                                   # warm-up
+    times = []
+    t_all = time.time()
+    for c in range(1, wl.n_chunks):
+        t0 = time.time()
+        chunk(c)
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
+            break
+    t_chunk = sum(times) / len(times)
+    utt_s = t_ref + wl.n_chunks * t_chunk
+    return {"value": 1.0 / utt_s, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} of {wl.n_chunks} one-second chunks of one utterance (DVAE+VQ, prefill 48 rows, "
+                      f"{STEPS_PER_CHUNK} decode steps each) + mel/Perceiver once; extrapolated to the full utterance",
+            "ms_per_chunk": t_chunk * 1e3, "ms_per_decode_token_est": t_chunk * 1e3 / (STEPS_PER_CHUNK + 2),
+            "rtf": utt_s / SRC_SECONDS, "host_cpus": os.cpu_count(), "cpu": platform.processor() or platform.machine()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    wl = Workload(device, rank)
+    for u in range(args.warmup):
+        wl.utterance(u)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    gathered = None
+    for u in range(args.steps):
+        toks = wl.utterance(u)
+        if dist is not None:                          # collect this wave's token ids on every rank
+            gathered = [torch.empty_like(toks) for _ in range(world)]
+            dist.all_gather(gathered, toks)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # latency / per-stage numbers from one recorded utterance (device events on the launch stream)
+        wl.utterance(0, record=True)
+        torch.cuda.synchronize()
+        first_ms = wl.ev[0].elapsed_time(wl.ev[1])
+        utt_ms = wl.ev[0].elapsed_time(wl.ev[2])
+        # per-kernel timing of the decode step: each class launched back to back across the layers between two
+        # HIP events on the launch stream (gvc_gpt_time_kernel); mean per launch, launch boundary included
+        S = wl.P + 1 + STEPS_PER_CHUNK // 2
+        tok = torch.zeros(1, device=device, dtype=torch.int32)
+        kern = []
+        for which in range(6):
+            avg, n = wl.eng.time_kernel(which, wl.slots, tok, 64 if which == 5 else 8)
+            per_step = 1 if which == 5 else wl.dims["n_layer"]
+            kern.append({"kernel": KERNEL_NAMES[which], "avg_us": avg, "launches_timed": n, "launches_per_step": per_step,
+                         "bytes": kernel_bytes(wl.dims, which, S)})
+        dom = max(range(6), key=lambda i: kern[i]["avg_us"] * kern[i]["launches_per_step"])
+        achieved = kern[dom]["bytes"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(KERNEL_NAMES[dom])
+        n_utts = args.steps * world
+        ms_step = dt / args.steps * 1e3
+        out = {
+            "metric": "utterances/s (streaming, 1 s chunks; with RTF and first-chunk latency)",
+            "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms,
+            "ms_per_utterance_device": utt_ms,
+            "config": {"workload": "GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])",
+                       "arch": "L=30 d=1024 H=4 V=1026 fp32, synthetic weights (train_genVC.py dims; no checkpoint ships)",
+                       "utterance": "10 s source @16 kHz (10 chunks x 49 content frames -> 13 codes), 3 s reference @24 kHz",
+                       "per_chunk": f"prefill {wl.P + 1} rows + {STEPS_PER_CHUNK} decode steps, tokens read back every {GROUP}",
+                       "excluded_from_timed_path": ["ContentVec (fairseq boundary, features are the input)",
+                                                    "HiFi-GAN vocoder (SURVEY f1, next)"],
+                       "parallelism": f"replicas x{world}, utterances sharded by rank, all_gather of token ids"},
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": kern[dom]["bytes"], "avg_us": kern[dom]["avg_us"],
+                         "decode_step_us": sum(k["avg_us"] * k["launches_per_step"] for k in kern)},
+            "kernels": kern,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gvc_sample": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32, _P, _P]),
     "gvc_gpt_generate": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32,
                                    C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
+    "gvc_gpt_time_kernel": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, c_f32p, c_i32p, _P]),
     "gvc_perceiver_create": (C.c_int, [C.POINTER(PerceiverDims), C.POINTER(_P)]),
     "gvc_perceiver_destroy": (C.c_int, [_P]),
     "gvc_perceiver_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
@@ -83,6 +84,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GenvcHipError(f"{LIB_PATH} not found: build it with `python -m genvc_amd.build` "
                                 "(there is no CPU fallback for the product path)")
+        import torch  # noqa: F401  (first: the HIP runtime must be the one torch loads, never two copies)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)

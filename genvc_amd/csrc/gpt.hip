@@ -172,6 +172,7 @@ struct gvc_gpt {
     GenCall* gen_call = nullptr;
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;   // B -> step graph
+    int prof_only = -1;               // gvc_gpt_time_kernel(): launch only this kernel class
 };
 
 static int gemv_init();
@@ -448,6 +449,9 @@ static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
 }
 
 // one decode step for a group of <= 8 streams whose scratch rows start at row0
+// gvc_gpt_time_kernel(): when prof_only >= 0 only that kernel class of the step is launched
+static inline bool prof_skip(const gvc_gpt* c, int which) { return c->prof_only >= 0 && c->prof_only != which; }
+
 static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
                         float* latent_out, int32_t* step_ctr, hipStream_t s) {
     const int d = c->dm.d_model;
@@ -463,35 +467,36 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
         A.out = qb;
         A.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
         A.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
-        if ((rc = launch_gemv<PRO_LN, EPI_QKV>(c, A, B, s))) return rc;
+        if (!prof_skip(c, 0) && (rc = launch_gemv<PRO_LN, EPI_QKV>(c, A, B, s))) return rc;
 
         AttnArgs T = gpt_attn_args(c, l, slots);
         T.q = qb; T.T = 1; T.base_len = c->st.seq_len; T.out = pb;
         if (c->prefetch) T.pf = prefetch_of(c, ly.proj_w, d, d);
-        if ((rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
+        if (!prof_skip(c, 1) && (rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.proj_w; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
         if (c->prefetch) A.pf = prefetch_of(c, ly.fc_w, 4 * d, d);
-        if ((rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
+        if (!prof_skip(c, 2) && (rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
         if (c->prefetch) A.pf = prefetch_of(c, ly.p2_w, d, 4 * d);
-        if ((rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
+        if (!prof_skip(c, 3) && (rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
         if (c->prefetch)
             A.pf = l + 1 < c->dm.n_layer ? prefetch_of(c, c->layers[l + 1].qkv_w, 3 * d, d)
                                          : prefetch_of(c, c->head_w, c->dm.vocab, d);
-        if ((rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
+        if (!prof_skip(c, 4) && (rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
     }
     GemvArgs A = base_args(c, slots, row0);
     A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
     A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
     A.out = logits_out; A.latent_out = latent_out; A.advance = 1; A.step_ctr = step_ctr;
     if (c->prefetch) A.pf = prefetch_of(c, c->layers[0].qkv_w, 3 * d, d);   // next step's first operand
+    if (prof_skip(c, 5)) return GVC_OK;
     return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
 }
 
@@ -687,3 +692,42 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     return GVC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// measurement hook (bench.py roofline): launch ONLY one kernel class of the decode step (0 qkv, 1 attention,
+// 2 attn c_proj, 3 mlp c_fc, 4 mlp c_proj, 5 head), layer after layer as the step does (so every launch
+// streams different weights, 1.5 GB apart in total: no cache reuse), n_steps times back to back on the
+// caller's stream between two hipEvents; returns the mean microseconds per launch.  HIP events resolve
+// single ~5 us kernels poorly (an empty event pair already measures ~4.7 us), so the mean over a long
+// back-to-back run is used; it includes the same-stream launch boundary, as rocprofv3's per-kernel
+// durations summed over a decode step do.  Synchronises the stream.
+// ---------------------------------------------------------------------------------------------
+extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slots, int32_t B, const int32_t* tok_in,
+                                   int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    GVC_REQUIRE(which >= 0 && which <= 5 && B >= 1 && B <= 8 && n_steps >= 1 && avg_us, GVC_ERR_ARG,
+                "time_kernel: bad argument");
+    hipStream_t s = (hipStream_t)sv;
+    hipEvent_t e0, e1;
+    GVC_CHECK_HIP(hipEventCreate(&e0));
+    GVC_CHECK_HIP(hipEventCreate(&e1));
+    c->prof_only = which;
+    rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s);      // warm-up pass
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < n_steps && rc == GVC_OK; ++i)
+        rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s);
+    (void)hipEventRecord(e1, s);
+    c->prof_only = -1;
+    hipError_t e = hipStreamSynchronize(s);
+    float ms = 0.f;
+    if (rc == GVC_OK && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    GVC_CHECK_HIP(e);
+    const int n = (which == 5 ? 1 : c->dm.n_layer) * n_steps;
+    *avg_us = ms * 1000.0f / (float)n;
+    if (n_launches) *n_launches = n;
+    return GVC_OK;
+}

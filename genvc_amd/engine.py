@@ -116,6 +116,13 @@ class GptEngine:
                                      tokens_out.shape[1], ptr(latents_out),
                                      latents_out.shape[1] if latents_out is not None else 0, stream()), "generate")
 
+    def time_kernel(self, which, slots, tok, n_steps):
+        """(mean us per launch, launches) of one kernel class of the decode step, launched back to back"""
+        avg, n = C.c_float(), C.c_int32()
+        check(lib().gvc_gpt_time_kernel(self._h, which, ptr(_i32(slots)), slots.shape[0], ptr(_i32(tok)), n_steps,
+                                        C.byref(avg), C.byref(n), stream()), "time_kernel")
+        return avg.value, n.value
+
 
 class PerceiverEngine:
     """PerceiverResampler.forward (reference layers/perceiver_encoder.py:265-276)."""

@@ -1,0 +1,238 @@
+"""`GPT` with the reference's constructor, method names and argument meaning
+(/root/reference/layers/gpt.py:87-621) for the inference path.  The module only holds the parameters
+(same names and shapes as the reference state dict, so `load_state_dict(ckpt['model'])` works) and
+drives libgenvc_hip through `GptEngine`; there is no PyTorch arithmetic fallback.
+
+Mapped entry points: init_gpt_for_inference (:197), get_style_emb (:351), forward(return_latent=True)
+(:375-508), compute_embeddings (:572), generate (:594), get_generator (:612), inference (:569).
+Training-only paths (losses, masks, eval_sample) raise NotImplementedError: out of scope.
+"""
+import torch
+from torch import nn
+
+from ..engine import GptEngine, sample_params
+from .perceiver_encoder import PerceiverResampler
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _p(*shape, std=0.02, ones=False):
+    t = torch.ones(*shape) if ones else torch.empty(*shape).normal_(std=std) if std else torch.zeros(*shape)
+    return nn.Parameter(t, requires_grad=False)
+
+
+class LearnedPositionEmbeddings(nn.Module):
+    """holds `emb.weight` [seq_len, dim] (reference gpt.py:21-40)"""
+
+    def __init__(self, seq_len, model_dim, init=0.02):
+        super().__init__()
+        self.emb = _Holder()
+        self.emb.weight = _p(seq_len, model_dim, std=init)
+        self.seq_len = seq_len
+
+
+def _conv1d(nin, nout):
+    m = _Holder()
+    m.weight = _p(nin, nout)            # HF Conv1D layout [in, out]
+    m.bias = _p(nout, std=0)
+    return m
+
+
+def _ln(d):
+    m = _Holder()
+    m.weight = _p(d, ones=True)
+    m.bias = _p(d, std=0)
+    return m
+
+
+class GPT(nn.Module):
+    def __init__(self, start_text_token=256, stop_text_token=257, layers=8, model_dim=512, heads=8,
+                 max_text_tokens=120, max_mel_tokens=250, max_prompt_tokens=70, max_conditioning_inputs=1,
+                 code_stride_len=1024, number_text_tokens=258, num_audio_tokens=1026, start_audio_token=1024,
+                 stop_audio_token=1025, train_solo_embeddings=False, checkpointing=False,
+                 average_conditioning_embeddings=False, fix_condition_embeddings=False, label_smoothing=0.0,
+                 perceiver_cond_length_compression=256):
+        super().__init__()
+        self.number_text_tokens = number_text_tokens
+        self.start_text_token, self.stop_text_token = start_text_token, stop_text_token
+        self.num_audio_tokens = num_audio_tokens
+        self.start_audio_token, self.stop_audio_token = start_audio_token, stop_audio_token
+        self.layers, self.heads, self.model_dim = layers, heads, model_dim
+        self.max_conditioning_inputs = max_conditioning_inputs
+        self.max_gen_mel_tokens = max_mel_tokens - max_conditioning_inputs - 2             # gpt.py:131
+        self.max_mel_tokens = max_mel_tokens + 2 + max_conditioning_inputs                 # :132
+        self.max_text_tokens = max_text_tokens + 2                                         # :133
+        self.max_prompt_tokens = max_prompt_tokens
+        self.code_stride_len = code_stride_len
+
+        d = model_dim
+        self.text_embedding = _Holder(); self.text_embedding.weight = _p(number_text_tokens, d)
+        self.mel_embedding = _Holder(); self.mel_embedding.weight = _p(num_audio_tokens, d)
+        self.mel_pos_embedding = LearnedPositionEmbeddings(self.max_mel_tokens, d)
+        self.text_pos_embedding = LearnedPositionEmbeddings(self.max_text_tokens, d)
+        self.gpt = _Holder()
+        self.gpt.h = nn.ModuleList()
+        for _ in range(layers):
+            blk = _Holder()
+            blk.ln_1, blk.ln_2 = _ln(d), _ln(d)
+            blk.attn = _Holder(); blk.attn.c_attn = _conv1d(d, 3 * d); blk.attn.c_proj = _conv1d(d, d)
+            blk.mlp = _Holder(); blk.mlp.c_fc = _conv1d(d, 4 * d); blk.mlp.c_proj = _conv1d(4 * d, d)
+            self.gpt.h.append(blk)
+        self.gpt.ln_f = _ln(d)
+        self.final_norm = _ln(d)
+        self.text_head = _Holder(); self.text_head.weight = _p(number_text_tokens, d); self.text_head.bias = _p(number_text_tokens, std=0)
+        self.mel_head = _Holder(); self.mel_head.weight = _p(num_audio_tokens, d); self.mel_head.bias = _p(num_audio_tokens, std=0)
+        # hyper-parameters hard-coded in the reference (gpt.py:179-188)
+        self.conditioning_perceiver = PerceiverResampler(dim=d, depth=4, dim_context=80, num_latents=32, dim_head=64,
+                                                         heads=8, ff_mult=4, use_flash_attn=False)
+        self.engine = None
+        self._prefix = None
+        self.max_slots = 8
+
+    # ------------------------------------------------------------------------------------------
+    def dims(self):
+        return dict(n_layer=self.layers, d_model=self.model_dim, n_head=self.heads,
+                    num_audio_tokens=self.num_audio_tokens, number_text_tokens=self.number_text_tokens,
+                    start_text_token=self.start_text_token, stop_text_token=self.stop_text_token,
+                    start_audio_token=self.start_audio_token, stop_audio_token=self.stop_audio_token,
+                    max_gen_mel_tokens=self.max_gen_mel_tokens, max_mel_pos=self.max_mel_tokens,
+                    max_text_pos=self.max_text_tokens, max_prompt_tokens=self.max_prompt_tokens,
+                    code_stride_len=self.code_stride_len,
+                    max_seq=self.max_prompt_tokens + self.max_mel_tokens + self.max_text_tokens + 1)   # gpt.py:198
+
+    def init_gpt_for_inference(self, kv_cache=True, use_deepspeed=False, max_slots=8, max_rows=4096):
+        """reference gpt.py:197-218: here = create the HIP context and repack the weights into it."""
+        if not kv_cache:
+            raise NotImplementedError("the HIP path always uses the KV cache")
+        if use_deepspeed:
+            raise NotImplementedError("DeepSpeed kernel injection is replaced by libgenvc_hip")
+        if self.engine is not None:
+            self.engine.close()
+        self.max_slots = max_slots
+        self.engine = GptEngine(self.dims(), max_slots=max_slots, max_rows=max_rows)
+        sd = {k: v for k, v in self.state_dict().items() if not k.startswith("conditioning_perceiver.")}
+        self.engine.bind(sd)
+        self.conditioning_perceiver.bind()
+        return self
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("call init_gpt_for_inference() first (reference inference/model_init.py:31)")
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def get_style_emb(self, cond_input, return_latent=False, seq_lens=None):
+        """cond_input (b,80,s) or (b,1,80,s) -> (b, d, 32)   (reference gpt.py:351-373)"""
+        if return_latent:
+            return cond_input.unsqueeze(1)
+        if cond_input.ndim == 4:
+            cond_input = cond_input.squeeze(1)
+        if seq_lens is not None:
+            raise NotImplementedError("perceiver masks are a training-only path")
+        return self.conditioning_perceiver(cond_input.permute(0, 2, 1).contiguous()).transpose(1, 2)
+
+    @torch.inference_mode()
+    def compute_embeddings(self, cond_latents, text_inputs):
+        """reference gpt.py:572-592: stores the prefix embeddings, returns the fake ids (1 ... 1, start)."""
+        self._need_engine()
+        self._prefix = self.engine.prefix_embeddings(cond_latents.to(torch.float32).contiguous(),
+                                                     text_inputs.to(torch.int32).contiguous())
+        B, P, _ = self._prefix.shape
+        ids = torch.full((B, P + 1), 1, dtype=torch.long, device=text_inputs.device)
+        ids[:, -1] = self.start_audio_token
+        return ids
+
+    def _start(self, fake_inputs, kw):
+        """prefill + device-side loop state for the stored prefix"""
+        if kw.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not on GenVC's inference path (num_beams=1)")
+        B, n0 = fake_inputs.shape
+        dev = fake_inputs.device
+        max_new = kw.get("max_new_tokens") or self.max_gen_mel_tokens                     # gpt.py:606,618
+        slots = torch.arange(B, device=dev, dtype=torch.int32)
+        ids = torch.empty(B, n0 + max_new + 8, device=dev, dtype=torch.int32)
+        ids[:, :n0] = fake_inputs.to(torch.int32)
+        st = dict(B=B, slots=slots, ids=ids,
+                  ids_len=torch.full((B,), n0, device=dev, dtype=torch.int32),
+                  finished=torch.zeros(B, device=dev, dtype=torch.int32),
+                  toks=torch.full((B, max_new), self.stop_audio_token, device=dev, dtype=torch.int32),
+                  lats=torch.empty(B, max_new, self.model_dim, device=dev, dtype=torch.float32),
+                  max_new=max_new, done=0)
+        samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
+                    top_p=kw.get("top_p", 1.0), top_k=kw.get("top_k", 0) if kw.get("do_sample", True) else 1)
+        st["params"] = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
+        self.engine.prefill(slots, self._prefix, want_outputs=False)
+        return st
+
+    def _advance(self, st, n):
+        """n graph-replayed (sample, decode) steps; returns True when every row has emitted the stop token"""
+        n = min(n, st["max_new"] - st["done"])
+        if n > 0:
+            self.engine.generate(st["slots"], st["ids"], st["ids_len"], st["finished"], st["params"], st["done"], n,
+                                 st["toks"], st["lats"])
+            st["done"] += n
+        return bool(st["finished"].all().item()) or st["done"] >= st["max_new"]
+
+    @torch.inference_mode()
+    def generate(self, cond_latents, text_inputs, **generate_kwargs):
+        """reference gpt.py:594-609 -> int64 [B, n_generated]; finished rows are padded with the stop token.
+        `group` (extra kwarg) = decode steps per host check of the finished flags."""
+        fake = self.compute_embeddings(cond_latents, text_inputs)
+        group = generate_kwargs.pop("group", 16)
+        st = self._start(fake, generate_kwargs)
+        while not self._advance(st, group):
+            pass
+        # the reference loop stops at the step where the last row emits 1025
+        toks = st["toks"][:, :st["done"]].long()
+        n = self._stop_len(toks)
+        self.last_latents = st["lats"][:, :n]
+        return toks[:, :n]
+
+    def _stop_len(self, toks):
+        """steps the reference loop runs: up to and including the step where the last row emits the stop token"""
+        is_stop = toks == self.stop_audio_token
+        if not bool(is_stop.any(1).all()):
+            return toks.shape[1]
+        return int(is_stop.long().argmax(1).max().item()) + 1
+
+    @torch.inference_mode()
+    def get_generator(self, fake_inputs, **generate_kwargs):
+        """reference gpt.py:612-621 + stream_generator.py:865: yields (tokens int64[B], latent float[B,d]) per step,
+        the EOS step included.  Steps run in groups of `stream_group` (default 8, the vocoder chunk of
+        inference_utils.py:195) with one host check of the finished flags per group."""
+        self._need_engine()
+        group = generate_kwargs.pop("stream_group", 8)
+        st = self._start(fake_inputs, generate_kwargs)
+        emitted = 0
+        while True:
+            end = self._advance(st, group)
+            toks = st["toks"][:, emitted:st["done"]].long()
+            n = toks.shape[1]
+            if end and n:
+                n = min(n, self._stop_len(st["toks"][:, :st["done"]].long()) - emitted)
+            for i in range(n):
+                yield toks[:, i], st["lats"][:, emitted + i]
+            emitted += n
+            if end:
+                return
+
+    def inference(self, cond_latents, text_inputs, **generate_kwargs):
+        return self.generate(cond_latents, text_inputs, **generate_kwargs)
+
+    @torch.inference_mode()
+    def forward(self, text_inputs, text_lengths, audio_codes, wav_lengths, cond_mels=None, cond_lens=None,
+                cond_latents=None, return_attentions=False, return_latent=False):
+        """Inference use of reference gpt.py:375-508: `return_latent=True` with `cond_latents` given
+        (inference_utils.py:71-76) -> latents [B,n,d] of the n = ceil(wav_lengths/1024) codes."""
+        self._need_engine()
+        if not return_latent or cond_latents is None or return_attentions:
+            raise NotImplementedError("only forward(..., cond_latents=..., return_latent=True) is on the inference path")
+        B, n = audio_codes.shape
+        if int(text_lengths.min()) != text_inputs.shape[1] or int(torch.ceil(wav_lengths / self.code_stride_len).min()) != n:
+            raise NotImplementedError("ragged text/code lengths are a training-only path")
+        prefix = self.engine.prefix_embeddings(cond_latents.to(torch.float32).contiguous(),
+                                               text_inputs.to(torch.int32).contiguous())
+        slots = torch.arange(B, device=audio_codes.device, dtype=torch.int32)
+        return self.engine.latents(slots, prefix, audio_codes.to(torch.int32).contiguous())

@@ -144,6 +144,14 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
                      int32_t n_steps, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
                      int32_t lat_stride, gvc_stream s);
 
+/* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
+ * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head
+ * GEMV) for every layer, n_steps times back to back on the stream between two hipEvents, and returns the
+ * mean microseconds per launch (same-stream launch boundary included) and the number of launches.
+ * Synchronises the stream; leaves the slots' caches in an undefined state (reset or prefill afterwards). */
+int gvc_gpt_time_kernel(gvc_gpt* ctx, int32_t which, const int32_t* slots, int32_t B, const int32_t* tok_in,
+                        int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream s);
+
 /* ------------------------------------------------------------------------------------------
  * Perceiver resampler.  Replaces layers/perceiver_encoder.py:PerceiverResampler.forward (:265-276)
  * as called by GPT.get_style_emb (gpt.py:351-373) with mask=None.
