@@ -1,0 +1,97 @@
+"""GPU: the reference-shaped Python surface (GPT / harness / offline driver) on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from genvc_amd import config as gcfg
+from genvc_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GREEDY = dict(do_sample=True, top_k=1, top_p=0.85, temperature=0.85, repetition_penalty=2.0, num_beams=1,
+              length_penalty=1.0)
+_m = {}
+
+
+def tiny_model(seed=3):
+    from genvc_amd.inference.model_init import model_init_synthetic
+    if seed not in _m:
+        _m.clear()
+        _m[seed] = model_init_synthetic(gcfg.default_config(tiny=True), seed=seed, device=DEV)[0]
+        _m[seed].config.top_k = 1
+    return _m[seed]
+
+
+def test_gpt_generate_generator_and_forward_match_reference(gold):
+    g = gold("gpt_tiny")
+    m = tiny_model(int(g["seed"]))
+    s, B, Tc = int(g["in_seed"]), int(g["B"]), int(g["Tc"])
+    cond = synth.uniform(s, "cond_latents", (B, 32, 256), 1.0).to(DEV)
+    codes = synth.integers(s, "content_codes", (B, Tc), 256).to(DEV)
+    n = g["tokens"].shape[1]
+    fake = m.gpt.compute_embeddings(cond, codes)
+    assert np.array_equal(fake.cpu().numpy(), g["fake_ids"])                    # 1 ... 1, 1024 (int64)
+    toks = m.gpt.generate(cond, codes, max_new_tokens=n, **GREEDY)
+    assert toks.dtype == torch.int64 and np.array_equal(toks.cpu().numpy(), g["tokens"])
+    # streaming generator: one (token, latent) pair per step
+    fake = m.gpt.compute_embeddings(cond, codes)
+    pairs = list(m.gpt.get_generator(fake, max_new_tokens=n, **GREEDY))
+    assert len(pairs) == n
+    assert np.array_equal(torch.stack([p[0] for p in pairs], 1).cpu().numpy(), g["tokens"])
+    lat = torch.stack([p[1] for p in pairs], 1)
+    np.testing.assert_allclose(lat[:, :, :32].cpu().numpy(), g["latents_slice"], atol=1e-4)
+    # latent re-pass with the reference's argument list (inference_utils.py:71-76)
+    gen = toks[:1]
+    rel = m.gpt(codes[:1], torch.tensor([Tc], device=DEV), gen, torch.tensor([n * 1024], device=DEV),
+                cond_latents=cond[:1], return_latent=True)
+    assert rel.shape == (1, n, 256)
+    np.testing.assert_allclose(rel[:, :, :32].cpu().numpy(), g["relatents"], atol=1e-4)
+    np.testing.assert_allclose(rel.cpu().numpy(), lat[:1].cpu().numpy(), atol=1e-4)
+    # style embedding with the reference's layout: (b, 80, s) -> (b, d, 32)
+    pg = gold("perceiver")
+    mel = synth.uniform(int(pg["seed"]), "mel_1_282", (1, 80, 282), 1.0).to(DEV)
+    np.testing.assert_allclose(m.gpt.get_style_emb(mel, None).cpu().numpy(), pg["tiny_1_282"], atol=5e-5)
+
+
+def test_generate_stops_like_the_reference_on_eos(gold):
+    g = gold("gpt_eos")
+    m = tiny_model(int(g["seed"]))
+    with torch.inference_mode():
+        m.gpt.mel_head.bias[1025] = float(g["stop_bias"])
+    m.gpt.init_gpt_for_inference()
+    cond = synth.uniform(int(g["seed"]), "cond_latents", (2, 32, 256), 1.0).to(DEV)
+    codes = synth.integers(int(g["seed"]), "content_codes", (2, 9), 256).to(DEV)
+    toks = m.gpt.generate(cond, codes, group=4, **GREEDY)
+    assert np.array_equal(toks.cpu().numpy(), g["tokens"])          # ragged EOS, pads after, loop ends with the last row
+    fake = m.gpt.compute_embeddings(cond, codes)
+    pairs = list(m.gpt.get_generator(fake, **GREEDY))
+    assert len(pairs) == g["tokens"].shape[1]
+    _m.clear()
+
+
+def test_harness_streaming_and_offline_agree():
+    from genvc_amd.inference.inference_utils import synthesize_utt, synthesize_utt_streaming
+    from genvc_amd.parallel_offline import convert_offline
+    m = tiny_model(3)
+    m.gpt.max_gen_mel_tokens = 40                                  # keep the test short (synthetic weights rarely stop)
+    src = synth.synth_audio(5, "src", 40000)                       # 2.5 s -> segments of 1 s, 1 s, 0.5 s
+    ref = synth.synth_audio(6, "ref", 72000)
+    st = synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+    nst = synthesize_utt(m, src, ref, seg_len=1.0, return_details=True)
+    toks_st = torch.cat(st["tokens"], 1)[0]
+    lat_st = torch.cat(st["latents"], 1)[0]
+    assert toks_st.shape[0] == lat_st.shape[0]                     # one latent per streamed token, EOS step included
+    keep = toks_st != m.gpt.stop_audio_token
+    assert torch.equal(toks_st[keep], torch.cat(nst["codes"]))     # same greedy codes on both paths
+    np.testing.assert_allclose(lat_st[keep].cpu().numpy(), nst["latents"][0].cpu().numpy(), atol=1e-4)
+    assert st["latency"] is not None and st["rtf"] > 0
+    # batched offline driver (world 1) == per-utterance results
+    srcs = [synth.synth_audio(10 + i, "src", 32000) for i in range(3)]
+    allt = convert_offline(m, srcs, ref, seg_len=1.0, micro_batch=2, rank=0, world=1, top_k=1)
+    assert allt.shape == (3, 2, 40) and allt.dtype == torch.int32
+    for i, s in enumerate(srcs):
+        one = synthesize_utt(m, s, ref, seg_len=1.0, return_details=True)["codes"]
+        for sidx, c in enumerate(one):
+            row = allt[i, sidx]
+            assert torch.equal(row[row != m.gpt.stop_audio_token].long(), c)
+    _m.clear()
