@@ -165,14 +165,28 @@ struct gvc_gpt {
     size_t kv_layer_stride = 0;       // floats per (layer, k|v)
     float *x = nullptr, *a = nullptr, *q = nullptr, *h = nullptr, *part = nullptr, *work = nullptr;
     long long work_cap = 0;
+    float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
+    int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
     float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
     int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step
     GptState st;
     int32_t *tok_buf = nullptr, *step_ctr = nullptr;
     GenCall* gen_call = nullptr;
     hipStream_t cap_stream = nullptr;
-    std::map<int, hipGraphExec_t> graphs;   // B -> step graph
+    std::map<int, hipGraphExec_t> graphs;   // 2*B + fused -> step graph
     int prof_only = -1;               // gvc_gpt_time_kernel(): launch only this kernel class
+    // step-long prefetcher (graph path only)
+    int use_prefetcher = 0;           // measured slower on MI355X; GVC_PREFETCHER=1 enables
+    PrefetchEntry* sched = nullptr;
+    int n_sched = 0;
+    int32_t* prog = nullptr;          // progress counter of the running step
+    int32_t* prog_active = nullptr;   // set while a step graph is being captured
+    int pf_mask = 15;                 // which operands the prefetcher pulls (1 proj, 2 fc, 4 mlp proj, 8 qkv)
+    int prog_base = 0;                // value of the counter at the start of the next step (host mirror)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long* dbg = nullptr; // GVC_DEBUG_STAMPS: [launch][8] in-kernel timestamps of the eager decode step
+    int dbg_n = 0;
 };
 
 static int gemv_init();
@@ -229,7 +243,8 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
         (rc = alloc_f(&c->a, rows * d)) || (rc = alloc_f(&c->q, rows * d)) || (rc = alloc_f(&c->h, rows * 4 * d)) ||
         (rc = alloc_f(&c->part, (size_t)D.max_slots * D.n_head * kAttnChunks * (hd + 4))) ||
         (rc = alloc_f(&c->work, (size_t)c->work_cap)) || (rc = alloc_f(&c->logits, (size_t)D.max_slots * V)) ||
-        (rc = alloc_f(&c->latent, (size_t)D.max_slots * d))) {
+        (rc = alloc_f(&c->latent, (size_t)D.max_slots * d)) || (rc = alloc_f(&c->x2, (size_t)D.max_slots * d)) ||
+        (rc = alloc_f(&c->part2, (size_t)D.max_slots * D.n_head * d))) {
         gvc_gpt_destroy(c);
         return rc;
     }
@@ -243,6 +258,18 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipMalloc((void**)&c->gen_call, sizeof(GenCall)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     if ((rc = gemv_init())) { gvc_gpt_destroy(c); return rc; }
+    if (getenv("GVC_PREFETCHER")) c->use_prefetcher = atoi(getenv("GVC_PREFETCHER"));
+    if (getenv("GVC_PF_MASK")) c->pf_mask = atoi(getenv("GVC_PF_MASK"));
+    if (getenv("GVC_FUSE_ATTN")) c->fuse_decode = atoi(getenv("GVC_FUSE_ATTN"));
+    GVC_CHECK_HIP(hipMalloc((void**)&c->prog, sizeof(int32_t)));
+    GVC_CHECK_HIP(hipMemset(c->prog, 0, sizeof(int32_t)));
+    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    if (getenv("GVC_DEBUG_STAMPS")) {
+        GVC_CHECK_HIP(hipMalloc((void**)&c->dbg, 4096 * 8 * sizeof(unsigned long long)));
+        GVC_CHECK_HIP(hipMemset(c->dbg, 0, 4096 * 8 * sizeof(unsigned long long)));
+    }
     *out = c;
     return GVC_OK;
 }
@@ -251,8 +278,13 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (!c) return GVC_OK;
     for (auto& kvp : c->graphs) hipGraphExecDestroy(kvp.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    if (c->side_stream) hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->sched) hipFree(c->sched);
+    if (c->prog) hipFree(c->prog);
     for (void* p : {(void*)c->wbase, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
-                    (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state,
+                    (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
         if (p) hipFree(p);
     delete c;
@@ -367,10 +399,15 @@ static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
     GemvGeom g;
     int rc = gemv_geom(c, A.N, A.K, &g);
     if (rc) return rc;
+    if (PRO == PRO_LN_SUM && g.wpb > 8) {            // this variant is compiled for <= 512 threads
+        g.wpb = 8 / g.ksplit * g.ksplit;
+        g.grid = cdiv(A.N * g.ksplit, g.wpb);
+    }
     const int NI = g.NI;
     A.ksplit = g.ksplit;
     A.wpb = g.wpb;
     A.B = B;
+    if (c->dbg && c->dbg_n < 4096) A.dbg = c->dbg + 8 * (size_t)(c->dbg_n++);
     const int BT = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
     const int grid = g.grid;
     const int wpb = g.wpb;
@@ -407,6 +444,7 @@ static int gemv_init() {
     if ((rc = gemv_allow_big_lds<PRO_LN, EPI_QKV>())) return rc;
     if ((rc = gemv_allow_big_lds<PRO_MERGE, EPI_RESID>())) return rc;
     if ((rc = gemv_allow_big_lds<PRO_LN, EPI_GELU>())) return rc;
+    if ((rc = gemv_allow_big_lds<PRO_LN_SUM, EPI_GELU>())) return rc;
     if ((rc = gemv_allow_big_lds<PRO_COPY, EPI_RESID>())) return rc;
     return gemv_allow_big_lds<PRO_LN2X, EPI_LOGITS>();
 }
@@ -426,6 +464,7 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     A.st = c->st;
     A.mel_emb = c->mel_emb;
     A.mel_pos_tab = c->mel_pos;
+    A.prog = c->prog_active;
     return A;
 }
 
@@ -445,6 +484,7 @@ static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
     T.slots = slots;
     T.causal = 1;
     T.scale = 1.0f / sqrtf((float)c->hd);
+    T.prog = c->prog_active;
     return T;
 }
 
@@ -452,8 +492,14 @@ static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
 // gvc_gpt_time_kernel(): when prof_only >= 0 only that kernel class of the step is launched
 static inline bool prof_skip(const gvc_gpt* c, int which) { return c->prof_only >= 0 && c->prof_only != which; }
 
+// can the fused attention + c_proj launch serve this call?  one stream, head_dim 256, and the caller
+// guarantees at most 8 * kFusedMaxKeys cached positions for the whole run (gvc_gpt_generate: ids_stride)
+static bool fused_ok(const gvc_gpt* c, int B, int max_keys) {
+    return c->fuse_decode && B == 1 && c->hd == 256 && c->dm.d_model % 16 == 0 && max_keys <= 8 * kFusedMaxKeys;
+}
+
 static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
-                        float* latent_out, int32_t* step_ctr, hipStream_t s) {
+                        float* latent_out, int32_t* step_ctr, hipStream_t s, bool fused = false) {
     const int d = c->dm.d_model;
     int rc;
     float* qb = c->q + (size_t)row0 * d;
@@ -469,6 +515,26 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
         A.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
         if (!prof_skip(c, 0) && (rc = launch_gemv<PRO_LN, EPI_QKV>(c, A, B, s))) return rc;
 
+        if (fused) {
+            // attention + head-split c_proj in one launch; c_fc's prologue sums the per-head partials
+            AttnProjArgs F;
+            memset(&F, 0, sizeof(F));
+            F.q = qb; F.kcache = A.kcache; F.vcache = A.vcache; F.slots = slots; F.seq_len = c->st.seq_len;
+            F.max_seq = c->dm.max_seq; F.n_head = c->dm.n_head; F.d = d; F.scale = 1.0f / sqrtf((float)c->hd);
+            F.Wp = ly.proj_w; F.part2 = c->part2 + (size_t)row0 * c->dm.n_head * d; F.prog = c->prog_active;
+            if (!prof_skip(c, 1)) {
+                hipLaunchKernelGGL((k_attn_proj<256>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
+                GVC_LAUNCH_CHECK();
+            }
+            A = base_args(c, slots, row0);
+            A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
+            A.part2 = F.part2; A.pbias = ly.proj_b; A.x2 = c->x2 + (size_t)row0 * d;
+            if (!prof_skip(c, 3) && (rc = launch_gemv<PRO_LN_SUM, EPI_GELU>(c, A, B, s))) return rc;
+            A = base_args(c, slots, row0);
+            A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb; A.xres = c->x2 + (size_t)row0 * d;
+            if (!prof_skip(c, 4) && (rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
+            continue;
+        }
         AttnArgs T = gpt_attn_args(c, l, slots);
         T.q = qb; T.T = 1; T.base_len = c->st.seq_len; T.out = pb;
         if (c->prefetch) T.pf = prefetch_of(c, ly.proj_w, d, d);
@@ -641,16 +707,51 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
 // ---------------------------------------------------------------------------------------------
 // generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
 // ---------------------------------------------------------------------------------------------
-static int build_step_graph(gvc_gpt* c, int B, hipGraphExec_t* out) {
+// prefetch schedule of one decode step.  Launch numbering inside a step graph (the progress counter):
+// 0 = k_sample is not counted; layer l: 5l+1 c_attn, 5l+2 attention, 5l+3 attn c_proj, 5l+4 c_fc, 5l+5 mlp c_proj;
+// 5L+1 head.  Each operand is requested one launch ahead of its consumer (two for the small attn c_proj),
+// so at most ~2 operands are in flight / resident in the 32 MB of L2.
+static int build_prefetch_schedule(gvc_gpt* c) {
+    if (c->sched) return GVC_OK;
+    const int L = c->dm.n_layer, d = c->dm.d_model;
+    std::vector<PrefetchEntry> e;
+    auto add = [&](int trig, const float* w, int N, int K) {
+        PrefetchEntry pe;
+        pe.trigger = trig;
+        pe.pf = prefetch_of(c, w, N, K);
+        if (pe.pf.base) e.push_back(pe);
+    };
+    for (int l = 0; l < L; ++l) {
+        const GptLayer& ly = c->layers[l];
+        if (c->pf_mask & 1) add(5 * l + 1, ly.proj_w, d, d);            // while c_attn runs
+        if (c->pf_mask & 2) add(5 * l + 2, ly.fc_w, 4 * d, d);          // while attention runs
+        if (c->pf_mask & 4) add(5 * l + 4, ly.p2_w, d, 4 * d);          // while c_fc runs
+        if (!(c->pf_mask & 8)) continue;
+        if (l + 1 < L) add(5 * l + 5, c->layers[l + 1].qkv_w, 3 * d, d);   // while mlp c_proj runs
+        else add(5 * l + 5, c->head_w, c->dm.vocab, d);
+    }
+    if (c->pf_mask & 8) add(5 * L + 1, c->layers[0].qkv_w, 3 * d, d);   // while the head runs: first operand of the next step
+    GVC_CHECK_HIP(hipMalloc((void**)&c->sched, e.size() * sizeof(PrefetchEntry)));
+    GVC_CHECK_HIP(hipMemcpy(c->sched, e.data(), e.size() * sizeof(PrefetchEntry), hipMemcpyHostToDevice));
+    c->n_sched = (int)e.size();
+    return GVC_OK;
+}
+
+static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) {
     hipStream_t cs = c->cap_stream;
+    int rc = GVC_OK;
+    const bool pf = c->use_prefetcher && B <= 8;
+    if (pf && (rc = build_prefetch_schedule(c))) return rc;
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    int rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
+    if (pf) c->prog_active = c->prog;        // every launch of the step bumps the progress counter
+    rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
     for (int g = 0; g < B && rc == GVC_OK; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         const bool last = g + 8 >= B;
         rc = decode_group(c, c->gen_call->slots + g, Bg, g, c->tok_buf + g, c->logits + (size_t)g * c->dm.vocab,
-                          c->latent + (size_t)g * c->dm.d_model, last ? c->step_ctr : nullptr, cs);
+                          c->latent + (size_t)g * c->dm.d_model, last ? c->step_ctr : nullptr, cs, fused);
     }
+    c->prog_active = nullptr;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (rc != GVC_OK) {
@@ -682,13 +783,28 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     GVC_CHECK_HIP(hipMemsetAsync(c->step_ctr, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_set_gen_call, dim3(1), dim3(64), 0, s, c->gen_call, sc, slots, B);
     GVC_LAUNCH_CHECK();
-    auto it = c->graphs.find(B);
+    // ids_stride bounds the cached positions of this run (prefix + 1 + every step the caller will ask for)
+    const bool fused = fused_ok(c, B, ids_stride);
+    const int key = B * 2 + (fused ? 1 : 0);
+    auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;
-        if ((rc = build_step_graph(c, B, &ge))) return rc;
-        it = c->graphs.emplace(B, ge).first;
+        if ((rc = build_step_graph(c, B, fused, &ge))) return rc;
+        it = c->graphs.emplace(key, ge).first;
     }
-    for (int i = 0; i < n_steps; ++i) GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
+    // hipGraph branches are serialised on this runtime, so the prefetcher is NOT a graph node: one launch per
+    // step on a side stream runs beside the step graph and follows it through the monotone progress counter
+    const bool pf = c->use_prefetcher && B <= 8 && c->sched;
+    const int per_step = 5 * c->dm.n_layer + 1;
+    for (int i = 0; i < n_steps; ++i) {
+        if (pf) {
+            static const int wgs = getenv("GVC_PF_WGS") ? atoi(getenv("GVC_PF_WGS")) : c->n_cu;
+            hipLaunchKernelGGL(k_step_prefetcher, dim3(wgs), dim3(64), 0, c->side_stream, c->sched, c->n_sched,
+                               c->prog, c->prog_base, 20000, c->use_prefetcher == 2 ? 0 : 1);
+            c->prog_base += per_step;
+        }
+        GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
+    }
     return GVC_OK;
 }
 
@@ -713,10 +829,11 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     GVC_CHECK_HIP(hipEventCreate(&e0));
     GVC_CHECK_HIP(hipEventCreate(&e1));
     c->prof_only = which;
-    rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s);      // warm-up pass
+    const bool fused = fused_ok(c, B, 0);       // the short-context variant bench.py's workload runs
+    rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s, fused);      // warm-up pass
     (void)hipEventRecord(e0, s);
     for (int i = 0; i < n_steps && rc == GVC_OK; ++i)
-        rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s);
+        rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, s, fused);
     (void)hipEventRecord(e1, s);
     c->prof_only = -1;
     hipError_t e = hipStreamSynchronize(s);
@@ -726,8 +843,18 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     GVC_CHECK_HIP(e);
-    const int n = (which == 5 ? 1 : c->dm.n_layer) * n_steps;
-    *avg_us = ms * 1000.0f / (float)n;
+    const int n = (which == 5 ? 1 : (fused && which == 2 ? 0 : c->dm.n_layer)) * n_steps;
+    *avg_us = n ? ms * 1000.0f / (float)n : 0.f;
     if (n_launches) *n_launches = n;
     return GVC_OK;
+}
+
+// debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
+extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {
+    if (!c || !c->dbg) return 0;
+    (void)hipDeviceSynchronize();
+    const int n = c->dbg_n < max_launches ? c->dbg_n : max_launches;
+    (void)hipMemcpy(host_out, c->dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    c->dbg_n = 0;
+    return n;
 }

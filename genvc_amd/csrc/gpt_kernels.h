@@ -25,7 +25,7 @@ struct Prefetch {
     int n_chunks;
 };
 
-enum Prologue { PRO_LN = 0, PRO_MERGE = 1, PRO_COPY = 2, PRO_LN2X = 3 };
+enum Prologue { PRO_LN = 0, PRO_MERGE = 1, PRO_COPY = 2, PRO_LN2X = 3, PRO_LN_SUM = 4 };
 enum Epilogue { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
 struct GemvArgs {
@@ -57,6 +57,11 @@ struct GemvArgs {
     int advance;                                // EPI_LOGITS: 1 -> seq_len++, mel_pos++ per slot
     int32_t* step_ctr;                          // EPI_LOGITS: nullable, ++ once per launch (generation loop)
     Prefetch pf;                                // next launch's weights (L2 warm-up by the extra wave)
+    unsigned long long* dbg;                    // null, or 8 timestamps (100 MHz wall clock) of this launch
+    int32_t* prog;                              // null, or the step's progress counter (++ when this launch starts)
+    // fused attention path (k_attn_proj): PRO_LN_SUM builds x' = x + pbias + sum_h part2[b][h] and stores it to x2;
+    // EPI_RESID then reads its residual from xres (= x2) instead of x
+    const float* part2; const float* pbias; float* x2; const float* xres;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -91,8 +96,9 @@ __device__ __forceinline__ void prefetch_wave(const Prefetch& P, int lane, int b
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
 
+// PRO_LN_SUM keeps more loads in flight per lane: it is launched with at most 8 waves (256-VGPR budget)
 template <int BT, int NI, int PRO, int EPI>
-__global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
+__global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const GemvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -102,6 +108,11 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
         return;                                // a terminated wave no longer counts at s_barrier
     }
     constexpr int KSEG = NI * 256;
+    if (A.prog && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool stamp = A.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    unsigned long long* dbg = A.dbg + (blockIdx.x == 0 ? 0 : 4);
+    if (stamp) dbg[0] = wall_clock64();
     float* a_lds = smem;                       // [BT][K]
     float* red = smem + BT * A.K;              // [wpb][BT] cross-wave partial sums (ksplit > 1)
 
@@ -118,15 +129,21 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
     float e_res = 0.f;
     int e_pos = 0;
     if constexpr (EPI == EPI_RESID) {
-        if (fin) e_res = A.x[(size_t)(lane * A.x_stride + A.x_off) * A.d + row];
+        if (fin) e_res = (A.xres ? A.xres : A.x)[(size_t)(lane * A.x_stride + A.x_off) * A.d + row];
     }
     if constexpr (EPI == EPI_QKV) {
         if (fin && row >= A.d) e_pos = A.st.seq_len[A.slots[lane]];
     }
 
+    // weights are read exactly once per step by exactly one wave: non-temporal (evict-first) loads keep
+    // them from displacing the activations / KV cache in L2 and MALL
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
     auto load_w = [&]() {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) w[i] = *reinterpret_cast<const float4*>(wp + i * 256);
+        for (int i = 0; i < NI; ++i) {
+            const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(wp + i * 256));
+            w[i] = make_float4(t.x, t.y, t.z, t.w);
+        }
     };
     // residual-stream row of stream b (layer 0 of a decode step builds it from the embeddings)
     auto load_x = [&](int b, float4 (&v)[NI]) {
@@ -191,7 +208,56 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
         }
     };
 
-    if constexpr (PRO == PRO_LN || PRO == PRO_LN2X) {
+    if constexpr (PRO == PRO_LN_SUM) {
+        // ONE stream (fused attention path): x' = x + c_proj bias + sum_h part2[h], then LayerNorm.  Wave g owns
+        // outputs [256g, 256g+256): all its operands are requested at once (one round trip), the row statistics
+        // are combined through LDS.
+        const bool has = wave < NI;
+        const int col = wave * 256 + lane * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f), g4 = t, c4 = t;
+        if (has) {
+            const float* xr = A.x + (size_t)A.x_off * A.d;
+            t = *reinterpret_cast<const float4*>(xr + col);
+            const float4 pb = *reinterpret_cast<const float4*>(A.pbias + col);
+            g4 = *reinterpret_cast<const float4*>(A.ln_w + col);
+            c4 = *reinterpret_cast<const float4*>(A.ln_b + col);
+            float4 ph[16];
+#pragma unroll
+            for (int h = 0; h < 16; ++h)
+                if (h < A.n_head) ph[h] = *reinterpret_cast<const float4*>(A.part2 + (size_t)h * A.d + col);
+            t.x += pb.x; t.y += pb.y; t.z += pb.z; t.w += pb.w;
+#pragma unroll
+            for (int h = 0; h < 16; ++h)
+                if (h < A.n_head) { t.x += ph[h].x; t.y += ph[h].y; t.z += ph[h].z; t.w += ph[h].w; }
+        }
+        load_w();
+        const float inv_d = 1.0f / (float)A.d;
+        if (has) {
+            if (blockIdx.x == 0) *reinterpret_cast<float4*>(A.x2 + (size_t)A.x_off * A.d + col) = t;
+            const float s1 = wave_sum((t.x + t.y) + (t.z + t.w));
+            if (lane == 0) red[wave] = s1;
+        }
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) mean += red[i];
+        mean *= inv_d;
+        if (has) {
+            const float a0 = t.x - mean, a1 = t.y - mean, a2 = t.z - mean, a3 = t.w - mean;
+            const float s2 = wave_sum((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+            if (lane == 0) red[NI + wave] = s2;
+        }
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) var += red[NI + i];
+        const float rstd = 1.0f / sqrtf(var * inv_d + 1e-5f);
+        if (has) {
+            t.x = (t.x - mean) * rstd * g4.x + c4.x; t.y = (t.y - mean) * rstd * g4.y + c4.y;
+            t.z = (t.z - mean) * rstd * g4.z + c4.z; t.w = (t.w - mean) * rstd * g4.w + c4.w;
+            *reinterpret_cast<float4*>(a_lds + col) = t;
+        }
+    } else if constexpr (PRO == PRO_LN || PRO == PRO_LN2X) {
         // one wave per stream (K == d == 256*NI); row, gain and bias are requested before the weights
         float4 v[NI], g[NI], c[NI];
         const bool mine = wave < A.B;
@@ -227,45 +293,50 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
         }
         if (first) load_w();
     } else {  // PRO_MERGE: combine the kAttnChunks partial softmax states of each head
+        // work item = (stream b, group of 256 outputs); items are spread over the workgroup's waves so the
+        // dependent loads of one item are a single round trip per wave
         const int pstride = A.head_dim + 4;   // (o[hd], m, l, pad): keeps float4 alignment
+        const int ngrp = A.K / 256;
         bool first = true;
-        for (int b = wave; b < BT; b += nwave) {
-            for (int k = lane * 4; k < A.K; k += 256) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                float mc[kAttnChunks], lc[kAttnChunks];
-                float4 oc[kAttnChunks];
-                if (b < A.B) {
-                    const int h = k / A.head_dim;
-                    const int j = k - h * A.head_dim;
-                    const float* pp = A.in + ((size_t)(b * A.n_head + h) * kAttnChunks) * pstride;
+        for (int item2 = wave; item2 < BT * ngrp; item2 += nwave) {
+            const int b = item2 / ngrp;
+            const int k = (item2 - b * ngrp) * 256 + lane * 4;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            float mc[kAttnChunks], lc[kAttnChunks];
+            float4 oc[kAttnChunks];
+            if (b < A.B) {
+                const int h = k / A.head_dim;
+                const int j = k - h * A.head_dim;
+                const float* pp = A.in + ((size_t)(b * A.n_head + h) * kAttnChunks) * pstride;
 #pragma unroll
-                    for (int c = 0; c < kAttnChunks; ++c) {
-                        mc[c] = pp[c * pstride + A.head_dim];
-                        lc[c] = pp[c * pstride + A.head_dim + 1];
-                        oc[c] = *reinterpret_cast<const float4*>(pp + c * pstride + j);
-                    }
+                for (int c = 0; c < kAttnChunks; ++c) {
+                    mc[c] = pp[c * pstride + A.head_dim];
+                    lc[c] = pp[c * pstride + A.head_dim + 1];
+                    oc[c] = *reinterpret_cast<const float4*>(pp + c * pstride + j);
                 }
-                if (first) { load_w(); first = false; }     // partials requested, then the weight stream
-                if (b < A.B) {
-                    float m = mc[0];
-#pragma unroll
-                    for (int c = 1; c < kAttnChunks; ++c) m = fmaxf(m, mc[c]);
-                    float L = 0.f;
-#pragma unroll
-                    for (int c = 0; c < kAttnChunks; ++c) {
-                        const float wgt = __expf(mc[c] - m);
-                        L += wgt * lc[c];
-                        o.x += wgt * oc[c].x; o.y += wgt * oc[c].y; o.z += wgt * oc[c].z; o.w += wgt * oc[c].w;
-                    }
-                    const float inv = 1.0f / L;
-                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-                }
-                *reinterpret_cast<float4*>(a_lds + b * A.K + k) = o;
             }
+            if (first) { load_w(); first = false; }     // partials requested, then the weight stream
+            if (b < A.B) {
+                float m = mc[0];
+#pragma unroll
+                for (int c = 1; c < kAttnChunks; ++c) m = fmaxf(m, mc[c]);
+                float L = 0.f;
+#pragma unroll
+                for (int c = 0; c < kAttnChunks; ++c) {
+                    const float wgt = __expf(mc[c] - m);
+                    L += wgt * lc[c];
+                    o.x += wgt * oc[c].x; o.y += wgt * oc[c].y; o.z += wgt * oc[c].z; o.w += wgt * oc[c].w;
+                }
+                const float inv = 1.0f / L;
+                o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+            }
+            *reinterpret_cast<float4*>(a_lds + b * A.K + k) = o;
         }
         if (first) load_w();
     }
+    if (stamp) dbg[1] = wall_clock64();         // prologue of this wave done
     __syncthreads();
+    if (stamp) dbg[2] = wall_clock64();         // input vectors staged by the whole workgroup
 
     // ---- dot products against the staged vectors ----
     float acc[BT];
@@ -297,6 +368,7 @@ __global__ __launch_bounds__(1024) void k_gemv(const GemvArgs A) {
         }
     }
 
+    if (stamp) dbg[3] = wall_clock64();         // weights consumed, reductions done
     // ---- epilogue: lane b finishes stream b ----
     if (fin) {
         float val = 0.f;
@@ -361,6 +433,7 @@ struct AttnArgs {
     float* out;                // DIRECT: [rows][out_stride] ; else partials [rows][heads][chunks][HD+4]
     int out_stride;
     Prefetch pf;               // next launch's weights, fetched by the 5th wave (blockDim 320)
+    int32_t* prog;             // null, or the step's progress counter (++ when this launch starts)
 };
 
 template <int HD, bool DIRECT>
@@ -371,6 +444,8 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
                           gridDim.x * gridDim.y * gridDim.z);
         return;
     }
+    if (A.prog && threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0)
+        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int LPK = HD / 4;          // lanes per key
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
     constexpr int NG = 4 * KPW;          // softmax states per block
@@ -457,6 +532,143 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
             pp[j] = acc;
             if (j == 0) { pp[HD] = M; pp[HD + 1] = L; }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused decode attention + attn c_proj for ONE stream with a short context (keys <= 8 * kFusedMaxKeys).
+// grid (d/16, heads), 8 waves.  Workgroup (i, h) recomputes the attention of head h (all its K/V rows are
+// requested up front: one memory round trip, the rows come from L2 for all but the first workgroup of a
+// head) and multiplies o_h into its 16 rows of the c_proj slice Wp[n][h*HD .. (h+1)*HD): a K-split of the
+// projection by head.  The `heads` partial vectors are summed by the next launch's prologue (PRO_LN_SUM), so
+// the separate attention launch and its boundary disappear.  Redundant attention work grows with the
+// context, hence the host only takes this path while 2*S*HD*4 bytes per workgroup stay small.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFusedMaxKeys = 16;       // keys per wave
+
+struct AttnProjArgs {
+    const float* q;            // [d] of the stream
+    const float* kcache; const float* vcache;   // layer base [slot][head][max_seq][HD]
+    const int32_t* slots; const int32_t* seq_len;
+    int max_seq, n_head, d;
+    float scale;
+    const float* Wp;           // attn c_proj, row-per-output [d][d]
+    float* part2;              // [heads][d] partial projections
+    int32_t* prog;
+};
+
+template <int HD>
+__global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
+    static_assert(HD == 256, "one key row = one float4 per lane");
+    __shared__ float sc[8 * kFusedMaxKeys];
+    __shared__ float l_s[8];
+    __shared__ __attribute__((aligned(16))) float o_s[8][HD];
+    __shared__ __attribute__((aligned(16))) float o_f[HD];
+    if (A.prog && threadIdx.x == 0 && blockIdx.x + blockIdx.y == 0)
+        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y;
+    const int slot = A.slots[0];
+    const int nk = A.seq_len[slot] + 1;                      // the key appended by this step included
+    const float4 q4 = *reinterpret_cast<const float4*>(A.q + h * HD + lane * 4);
+    const size_t head_off = ((size_t)slot * A.n_head + h) * A.max_seq * HD + lane * 4;
+    const float* kp = A.kcache + head_off;
+    const float* vp = A.vcache + head_off;
+    float4 kr[kFusedMaxKeys], vr[kFusedMaxKeys];
+#pragma unroll
+    for (int j = 0; j < kFusedMaxKeys; ++j) {
+        const int key = wave + 8 * j;            // wave-uniform: rows past the context are not requested at all
+        kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key < nk) kr[j] = *reinterpret_cast<const float4*>(kp + (size_t)key * HD);
+    }
+#pragma unroll
+    for (int j = 0; j < kFusedMaxKeys; ++j) {
+        const int key = wave + 8 * j;
+        vr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key < nk) vr[j] = *reinterpret_cast<const float4*>(vp + (size_t)key * HD);
+    }
+    // this wave's two rows of the head's c_proj slice (streamed once, non-temporal)
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    const int row0 = blockIdx.x * 16 + wave * 2;
+    f32x4_nt w0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(A.Wp + (size_t)row0 * A.d + h * HD + lane * 4));
+    f32x4_nt w1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(A.Wp + (size_t)(row0 + 1) * A.d + h * HD + lane * 4));
+
+    float s[kFusedMaxKeys];
+#pragma unroll
+    for (int j = 0; j < kFusedMaxKeys; ++j) {
+        const int key = wave + 8 * j;
+        s[j] = key < nk ? wave_sum(dot4(q4, kr[j])) * A.scale : -INFINITY;
+        if (lane == 0) sc[key] = s[j];
+    }
+    __syncthreads();
+    float m = fmaxf(sc[lane], sc[lane + 64]);                // 8 * 16 = 128 scores
+    m = wave_max(m);
+    float l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < kFusedMaxKeys; ++j) {
+        const float p = __expf(s[j] - m);                    // masked keys: exp(-inf) = 0
+        l += p;
+        o.x = fmaf(p, vr[j].x, o.x); o.y = fmaf(p, vr[j].y, o.y);
+        o.z = fmaf(p, vr[j].z, o.z); o.w = fmaf(p, vr[j].w, o.w);
+    }
+    *reinterpret_cast<float4*>(&o_s[wave][lane * 4]) = o;
+    if (lane == 0) l_s[wave] = l;
+    __syncthreads();
+    if (threadIdx.x < HD) {
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { L += l_s[w]; acc += o_s[w][threadIdx.x]; }
+        o_f[threadIdx.x] = acc / L;
+    }
+    __syncthreads();
+    const float4 of = *reinterpret_cast<const float4*>(&o_f[lane * 4]);
+    float d0 = fmaf(w0.x, of.x, fmaf(w0.y, of.y, fmaf(w0.z, of.z, w0.w * of.w)));
+    float d1 = fmaf(w1.x, of.x, fmaf(w1.y, of.y, fmaf(w1.z, of.z, w1.w * of.w)));
+    d0 = wave_sum(d0);
+    d1 = wave_sum(d1);
+    if (lane == 0) {
+        A.part2[(size_t)h * A.d + row0] = d0;
+        A.part2[(size_t)h * A.d + row0 + 1] = d1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step-long weight prefetcher (one launch per decode step on a side stream, concurrent with the step graph).
+// One single-wave workgroup per CU polls the step's progress counter; when launch number `trigger` has
+// started it pulls the operand of a LATER launch from HBM into its XCD's L2 (chunk cb goes to a workgroup
+// with cb % 8 == its own index % 8, matching the consumer's observed placement), so the consumer's
+// non-temporal weight loads hit L2 and HBM keeps streaming across launch boundaries.  Pure loads: results
+// never depend on it; the spin is bounded.
+// ---------------------------------------------------------------------------------------------
+struct PrefetchEntry {
+    int trigger;            // issue when *prog >= trigger
+    Prefetch pf;
+};
+
+static __global__ __launch_bounds__(64) void k_step_prefetcher(const PrefetchEntry* sched, int n_entries, const int32_t* prog,
+                                                               int base, int max_polls, int fetch) {
+    const int lane = threadIdx.x;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t sink = {0.f, 0.f, 0.f, 0.f};
+    const int r = blockIdx.x & 7;
+    const int nb_r = (gridDim.x - r + 7) >> 3;
+    const int i = blockIdx.x >> 3;
+    for (int e = 0; e < n_entries; ++e) {
+        const int trig = base + sched[e].trigger;     // the counter is monotone over the steps of a context
+        int polls = 0;
+        while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - trig < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++polls > max_polls) return;        // the step is not progressing: give up quietly
+        }
+        const Prefetch P = sched[e].pf;
+        if (!fetch) continue;
+        for (int cb = r + 8 * i; cb < P.n_chunks; cb += 8 * nb_r) {
+            const char* p = P.base + (size_t)cb * P.chunk_bytes;
+            for (int off = lane * 16; off < P.chunk_bytes; off += 64 * 16)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p + off) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
     }
 }
 

@@ -138,6 +138,8 @@ int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride,
  * the current logits, stores it at tokens_out[b*tok_stride + i0 + i] and the latent that predicted
  * it at latents_out[(b*lat_stride + i0 + i)*d], then runs the decode step that consumes it.
  * ids / ids_len / finished as in gvc_sample (the caller initialises them from compute_embeddings).
+ * ids_stride must cover the whole run of the stream (prefix + 1 + all steps the caller will request): it is the
+ * bound on cached positions from which the library picks the short-context kernel variant.
  * ------------------------------------------------------------------------------------------ */
 int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                      int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
