@@ -32,6 +32,12 @@ class DvaeDims(C.Structure):
                                          "codebook_dim", "num_tokens", "max_batch", "max_frames")]
 
 
+class HifiganDims(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("up_init_ch", C.c_int32), ("n_ups", C.c_int32), ("up_rates", C.c_int32 * 4),
+                ("up_kernels", C.c_int32 * 4), ("n_kernels", C.c_int32), ("res_kernels", C.c_int32 * 4),
+                ("res_dilations", (C.c_int32 * 2) * 4), ("max_batch", C.c_int32), ("max_frames", C.c_int32)]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     "gvc_version": (C.c_int, []),
@@ -63,6 +69,12 @@ _SIGNATURES = {
     "gvc_dvae_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "gvc_dvae_missing_weights": (C.c_int, [_P]),
     "gvc_dvae_encode": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_hifigan_create": (C.c_int, [C.POINTER(HifiganDims), C.POINTER(_P)]),
+    "gvc_hifigan_destroy": (C.c_int, [_P]),
+    "gvc_hifigan_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "gvc_hifigan_missing_weights": (C.c_int, [_P]),
+    "gvc_hifigan_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "gvc_hifigan_forward_latents": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gvc_vq_argmin": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 }
 

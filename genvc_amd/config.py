@@ -21,6 +21,12 @@ DEFAULT_CONTENT_DVAE = dict(num_channels=256, num_tokens=256, codebook_dim=512, 
 # configs/genVC_train_configs.py:76-80
 DEFAULT_SAMPLING = dict(temperature=0.85, length_penalty=1.0, repetition_penalty=2.0, top_k=15, top_p=0.85)
 
+# configs/vocoder_configs.py:7-20 (HiFi-GAN generator, ResBlock2)
+DEFAULT_VOCODER = dict(input_feat_dim=1024, upsample_initial_channel=256, resblock_kernel_sizes=[3, 5, 7],
+                       resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]], upsample_rates=[8, 8, 4],
+                       upsample_kernel_sizes=[16, 16, 8], resblock_type="2", hop_length=256)
+TINY_VOCODER = dict(DEFAULT_VOCODER, input_feat_dim=256, upsample_initial_channel=64)
+
 TINY_MODEL_ARGS = dict(DEFAULT_MODEL_ARGS, gpt_layers=2, gpt_n_model_channels=256, gpt_n_heads=4)
 TINY_CONTENT_DVAE = dict(DEFAULT_CONTENT_DVAE, codebook_dim=64, hidden_dim=32, num_resnet_blocks=1)
 
@@ -68,6 +74,7 @@ def default_config(tiny=False):
     cfg = dict(
         model_args=copy.deepcopy(TINY_MODEL_ARGS if tiny else DEFAULT_MODEL_ARGS),
         content_dvae_config=copy.deepcopy(TINY_CONTENT_DVAE if tiny else DEFAULT_CONTENT_DVAE),
+        vocoder_config=copy.deepcopy(TINY_VOCODER if tiny else DEFAULT_VOCODER),
         audio=dict(sample_rate=24000),
         **DEFAULT_SAMPLING,
     )

@@ -11,6 +11,7 @@
 namespace gvc {
 
 enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_RELU = 2 };
+enum GemmAAct { AACT_NONE = 0, AACT_LRELU = 1 };   // activation applied to A while it is staged (HiFi-GAN)
 
 struct GemmEpi {
     const float* bias;       // [N] or null
@@ -18,6 +19,8 @@ struct GemmEpi {
     const float* resid;      // [M][ldr] or null (may alias C for in-place residual)
     int ldr;
     long long resid_batch_stride;
+    const float* resid2;     // second residual with the layout of `resid` (HiFi-GAN resblock sum), or null
+    float out_scale;         // 0 = none; otherwise the stored value is multiplied by it
     // GPT QKV scatter (prefill): n < d -> q[m][n]; else K/V cache rows
     int qkv;                 // 1 -> scatter mode, C is the q buffer [M][d]
     int d, n_head, head_dim, max_seq, T;
@@ -30,6 +33,10 @@ struct GemmArgs {
     const float* Wt; int ldw;
     float* C; int ldc; long long c_batch_stride;
     int M, N, K;
+    // implicit im2col for dilated convolutions over a time-major buffer: when conv_cin > 0, column k of A is
+    // (tap = k / conv_cin, ci = k % conv_cin) and lives at A[m*lda + tap*conv_tap_stride + ci]
+    int conv_cin, conv_tap_stride;
+    int a_act; float a_slope;       // GemmAAct applied to A elements as they are loaded
     int SK;                  // split-K factor; >1: C unused, partials to `work`
     float* work;             // [batch][SK][M][N]
     GemmEpi e;
@@ -55,6 +62,8 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, 
         return;
     }
     if (e.resid) v += e.resid[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
+    if (e.resid2) v += e.resid2[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
+    if (e.out_scale != 0.f) v *= e.out_scale;
     G.C[batch * G.c_batch_stride + (size_t)m * G.ldc + n] = v;
 }
 

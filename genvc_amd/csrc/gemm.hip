@@ -27,8 +27,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int k = kbeg + kt * BK + c4;
             const int m = m0 + r, n = n0 + r;
-            ra[j] = (m < G.M && k < kend) ? *reinterpret_cast<const float4*>(Ab + (size_t)m * G.lda + k)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            size_t aoff = (size_t)m * G.lda + k;
+            if (G.conv_cin > 0) {       // a float4 never straddles a tap (conv_cin % 4 == 0)
+                const int tap = k / G.conv_cin;
+                aoff = (size_t)m * G.lda + (size_t)tap * G.conv_tap_stride + (k - tap * G.conv_cin);
+            }
+            ra[j] = (m < G.M && k < kend) ? *reinterpret_cast<const float4*>(Ab + aoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (G.a_act == AACT_LRELU) {
+                ra[j].x = ra[j].x > 0.f ? ra[j].x : ra[j].x * G.a_slope; ra[j].y = ra[j].y > 0.f ? ra[j].y : ra[j].y * G.a_slope;
+                ra[j].z = ra[j].z > 0.f ? ra[j].z : ra[j].z * G.a_slope; ra[j].w = ra[j].w > 0.f ? ra[j].w : ra[j].w * G.a_slope;
+            }
             rb[j] = (n < G.N && k < kend) ? *reinterpret_cast<const float4*>(G.Wt + (size_t)n * G.ldw + k)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -96,8 +104,8 @@ __global__ void k_splitk_epilogue(const GemmArgs G) {
 }
 
 int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
-    GVC_REQUIRE(G.K % 4 == 0 && G.lda % 4 == 0 && G.ldw % 4 == 0, GVC_ERR_ARG,
-                "gemm: K/lda/ldw must be multiples of 4 (K=%d lda=%d ldw=%d)", G.K, G.lda, G.ldw);
+    GVC_REQUIRE(G.K % 4 == 0 && G.lda % 4 == 0 && G.ldw % 4 == 0 && G.conv_cin % 4 == 0 && G.conv_tap_stride % 4 == 0,
+                GVC_ERR_ARG, "gemm: K/lda/ldw/conv strides must be multiples of 4 (K=%d lda=%d ldw=%d)", G.K, G.lda, G.ldw);
     const int tm = cdiv(G.M, BM), tn = cdiv(G.N, BN);
     const long long tiles = (long long)tm * tn * batch;
     int SK = 1;

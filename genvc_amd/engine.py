@@ -256,3 +256,72 @@ def vq_argmin(x, embed):
     check(lib().gvc_vq_argmin(ptr(_f32(x)), ptr(_f32(embed)), N, dim, embed.shape[1], ptr(idx), ptr(work), stream()),
           "vq_argmin")
     return idx
+
+
+class HifiganEngine:
+    """HiFiGAN.forward (reference layers/hifigan.py:218-233) and the latent entry point with the x4 interpolation."""
+
+    def __init__(self, cfg, max_batch=2, max_frames=2560):
+        self.cfg = dict(cfg)
+        d = _lib.HifiganDims()
+        d.in_dim, d.up_init_ch = cfg["input_feat_dim"], cfg["upsample_initial_channel"]
+        d.n_ups, d.n_kernels = len(cfg["upsample_rates"]), len(cfg["resblock_kernel_sizes"])
+        for i, (r, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+            d.up_rates[i], d.up_kernels[i] = r, k
+        for j, (k, dl) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
+            d.res_kernels[j] = k
+            d.res_dilations[j][0], d.res_dilations[j][1] = dl
+        d.max_batch, d.max_frames = max_batch, max_frames
+        self.total_up = 1
+        for r in cfg["upsample_rates"]:
+            self.total_up *= r
+        self.in_dim = cfg["input_feat_dim"]
+        self._h = C.c_void_p()
+        check(lib().gvc_hifigan_create(C.byref(d), C.byref(self._h)), "gvc_hifigan_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_hifigan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights, prefix=""):
+        """weights: reference state dict; weight-norm pairs (weight_g, weight_v) are folded here (loader plumbing)."""
+        sd = {k[len(prefix):]: v for k, v in weights.items() if k.startswith(prefix) and torch.is_tensor(v)}
+        folded = {}
+        for k, v in sd.items():
+            if k.endswith(".weight_v"):
+                g = sd[k[:-2] + "_g"]
+                norm = v.float().pow(2).sum(dim=tuple(range(1, v.dim())), keepdim=True).sqrt()
+                folded[k[:-9] + ".weight"] = (g.float() * v.float() / norm)
+            elif k.endswith(".weight_g"):
+                continue
+            else:
+                folded[k] = v
+        for name, t in folded.items():
+            t = _f32(t.detach().to(torch.float32).contiguous())
+            check(lib().gvc_hifigan_bind_weight(self._h, name.encode(), ptr(t), t.numel(), stream()), f"bind {name}")
+        torch.cuda.current_stream().synchronize()
+        missing = lib().gvc_hifigan_missing_weights(self._h)
+        if missing:
+            raise _lib.GenvcHipError(f"{missing} HiFi-GAN weight tensors missing after bind")
+
+    def forward(self, x):
+        """x [B,in_dim,T] -> [B,1,T*256]"""
+        B, _, T = x.shape
+        wav = torch.empty(B, 1, T * self.total_up, device=x.device, dtype=torch.float32)
+        check(lib().gvc_hifigan_forward(self._h, ptr(_f32(x)), B, T, ptr(wav), stream()), "hifigan_forward")
+        return wav
+
+    def forward_latents(self, latents, scale=4):
+        """latents [B,n,in_dim] -> [B,1,n*scale*256]  (F.interpolate(scale, 'linear') fused in front)"""
+        B, n, _ = latents.shape
+        wav = torch.empty(B, 1, n * scale * self.total_up, device=latents.device, dtype=torch.float32)
+        check(lib().gvc_hifigan_forward_latents(self._h, ptr(_f32(latents)), B, n, scale, ptr(wav), stream()),
+              "hifigan_forward_latents")
+        return wav

@@ -3,8 +3,8 @@
 stop-token stripping (:68), streaming groups of `stream_chunk_size` tokens with the EOS-step latent
 included (:187-207), cross-fade of vocoder chunks (:4-21), latency / RTF bookkeeping (:148, 208-216).
 
-The HiFi-GAN vocoder is SURVEY.md row f1 ("next"): when `model.hifigan` is None the functions return the
-acoustic latents (what the vocoder would consume) instead of a waveform.
+The vocoder call (x4 linear interpolation + HiFi-GAN) runs on libgenvc_hip; when
+`model.hifigan` is None the functions return the acoustic latents instead of a waveform.
 """
 import time
 
@@ -45,9 +45,13 @@ def _sampling_kwargs(model):
 
 
 def _vocode(model, latents):
-    """latents [1,n,d] -> waveform (reference :81-87) or the latents themselves without a vocoder"""
+    """latents [1,n,d] -> waveform: F.interpolate(scale_factor=hifigan_scale_factor, mode='linear') + HiFi-GAN
+    (reference :81-87, :196-202); both run inside one library call.  None without a vocoder."""
     if model.hifigan is None:
         return None
+    scale = int(model.hifigan_scale_factor)
+    if hasattr(model.hifigan, "forward_latents") and scale == model.hifigan_scale_factor:
+        return model.hifigan.forward_latents(latents, scale)
     mel_input = F.interpolate(latents.transpose(1, 2), scale_factor=[model.hifigan_scale_factor], mode="linear").squeeze(1)
     return model.hifigan(mel_input)
 

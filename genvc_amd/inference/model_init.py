@@ -11,6 +11,7 @@ from .. import config as gcfg
 from ..layers.content_processor import SyntheticContentExtractor
 from ..layers.dvae import DiscreteVAE
 from ..layers.gpt import GPT
+from ..layers.hifigan import HiFiGAN
 from ..utils import DEFAULT_MEL_NORM_FILE, TorchMelSpectrogram
 
 
@@ -35,8 +36,13 @@ class GenVCModel(nn.Module):
         self.content_sample_rate = c.get("dvae_sample_rate", 16000)
         # ContentVec is the un-vendored fairseq boundary; a real extractor can be passed in
         self.content_extractor = content_extractor or SyntheticContentExtractor(c.num_channels)
-        self.hifigan = hifigan                                            # "next" row f1; None -> latents only
-        self.hifigan_scale_factor = a.gpt_code_stride_len / 256          # hifigan_trainer.py:56 (hop_length 256)
+        v = config.get("vocoder_config")
+        if hifigan is None and v is not None:                             # hifigan_trainer.py:47-55
+            hifigan = HiFiGAN(v.input_feat_dim, v.upsample_initial_channel, v.resblock_kernel_sizes,
+                              v.resblock_dilation_sizes, v.upsample_rates, v.upsample_kernel_sizes,
+                              resblock_type=v.get("resblock_type", "2"))
+        self.hifigan = hifigan
+        self.hifigan_scale_factor = a.gpt_code_stride_len / (v.get("hop_length", 256) if v is not None else 256)  # :56
         self.torch_mel_spectrogram_style_encoder = TorchMelSpectrogram(
             filter_length=2048, hop_length=256, win_length=1024, normalize=False,
             sampling_rate=config.audio.sample_rate, mel_fmin=0, mel_fmax=8000, n_mel_channels=80,
@@ -76,6 +82,8 @@ def _finish(model, device, max_slots):
     model.to(device)
     model.gpt.init_gpt_for_inference(max_slots=max_slots)
     model.content_dvae.bind()
+    if model.hifigan is not None:
+        model.hifigan.bind()
     return model
 
 
@@ -101,6 +109,9 @@ def model_init_synthetic(config=None, seed=1, device="cuda", max_slots=8):
     w = {"gpt." + k: v for k, v in synth.make_weights(seed, synth.gpt_weight_spec(dims), device=device).items()}
     w.update({"content_dvae." + k: v for k, v in
               synth.make_weights(seed, synth.dvae_weight_spec(config.content_dvae_config), device=device).items()})
+    if model.hifigan is not None:
+        w.update({"hifigan." + k: v for k, v in
+                  synth.make_weights(seed, synth.hifigan_weight_spec(config.vocoder_config), device=device).items()})
     model.to(device)
     missing, unexpected = model.load_state_dict(w, strict=False)
     assert not unexpected, unexpected

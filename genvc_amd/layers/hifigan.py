@@ -1,0 +1,64 @@
+"""HiFi-GAN generator with the reference's constructor and `forward(x[B,d,T]) -> [B,1,256T]`
+(/root/reference/layers/hifigan.py:160-233) on libgenvc_hip (gvc_hifigan_forward).  Holds the
+weight-norm parametrised tensors under the reference's names (conv_pre.weight_g/_v, ups.{i}.*, resblocks.*)."""
+import torch
+from torch import nn
+
+from ..engine import HifiganEngine
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _wn(shape, bias_n):
+    m = _Holder()
+    m.weight_g = nn.Parameter(torch.ones(shape[0], 1, 1), requires_grad=False)
+    m.weight_v = nn.Parameter(torch.empty(*shape).normal_(std=0.01), requires_grad=False)
+    m.bias = nn.Parameter(torch.zeros(bias_n), requires_grad=False)
+    return m
+
+
+class HiFiGAN(nn.Module):
+    def __init__(self, input_feat_dim, upsample_initial_channel, resblock_kernel_sizes, resblock_dilation_sizes,
+                 upsample_rates, upsample_kernel_sizes, resblock_type="1"):
+        super().__init__()
+        if str(resblock_type) != "2":
+            raise NotImplementedError("GenVC's vocoder uses ResBlock2 (configs/vocoder_configs.py:20)")
+        self.cfg = dict(input_feat_dim=input_feat_dim, upsample_initial_channel=upsample_initial_channel,
+                        resblock_kernel_sizes=list(resblock_kernel_sizes),
+                        resblock_dilation_sizes=[list(d) for d in resblock_dilation_sizes],
+                        upsample_rates=list(upsample_rates), upsample_kernel_sizes=list(upsample_kernel_sizes))
+        ch = upsample_initial_channel
+        self.conv_pre = _wn((ch, input_feat_dim, 7), ch)
+        self.ups = nn.ModuleList()
+        self.resblocks = nn.ModuleList()
+        for r, k in zip(upsample_rates, upsample_kernel_sizes):
+            self.ups.append(_wn((ch, ch // 2, k), ch // 2))
+            ch //= 2
+            for kk in resblock_kernel_sizes:
+                rb = _Holder()
+                rb.convs = nn.ModuleList([_wn((ch, ch, kk), ch), _wn((ch, ch, kk), ch)])
+                self.resblocks.append(rb)
+        self.conv_post = _wn((1, ch, 7), 1)
+        self._engine = None
+
+    def bind(self, max_batch=2, max_frames=2560):
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = HifiganEngine(self.cfg, max_batch=max_batch, max_frames=max_frames)
+        self._engine.bind(dict(self.state_dict()))
+        return self
+
+    @torch.inference_mode()
+    def forward(self, x):
+        if self._engine is None:
+            self.bind()
+        return self._engine.forward(x.to(torch.float32).contiguous())
+
+    @torch.inference_mode()
+    def forward_latents(self, latents, scale=4):
+        """latents [B,n,d] -> wav; fuses the harness's F.interpolate(scale_factor=4, mode='linear')"""
+        if self._engine is None:
+            self.bind()
+        return self._engine.forward_latents(latents.to(torch.float32).contiguous(), scale)

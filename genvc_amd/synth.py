@@ -139,11 +139,36 @@ def dvae_weight_spec(cfg, prefix=""):
     return spec
 
 
+def hifigan_weight_spec(cfg, prefix=""):
+    """HiFi-GAN generator with weight-norm parametrisation, named as the reference state dict
+    (reference layers/hifigan.py:160-216): conv_pre, ups.{i}, resblocks.{i*nk+j}.convs.{0,1}, conv_post."""
+    spec = {}
+    ch = cfg["upsample_initial_channel"]
+
+    def wn(name, shape, g_mean):
+        spec[prefix + name + ".weight_g"] = ((shape[0], 1, 1), ("wn_g", g_mean))
+        spec[prefix + name + ".weight_v"] = (shape, "conv")
+        spec[prefix + name + ".bias"] = ((shape[1] if name.startswith("ups.") else shape[0],), "bias")
+
+    wn("conv_pre", (ch, cfg["input_feat_dim"], 7), 1.0)
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (r, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        wn(f"ups.{i}", (ch, ch // 2, k), 2.0)                      # ConvTranspose1d weight [Cin, Cout, k]
+        ch //= 2
+        for j, kk in enumerate(cfg["resblock_kernel_sizes"]):
+            for q in range(2):
+                wn(f"resblocks.{i * nk + j}.convs.{q}", (ch, ch, kk), 0.5)
+    wn("conv_post", (1, ch, 7), 1.0)
+    return spec
+
+
 def make_weights(seed, spec, device="cpu", head_scale=0.05):
     """Materialise a spec.  Scales: matrices N(0,0.02)-like, LayerNorm gains near 1."""
     out = {}
     for name, (shape, kind) in spec.items():
-        if kind == "ln_w":
+        if isinstance(kind, tuple) and kind[0] == "wn_g":
+            out[name] = uniform(seed, name, shape, 0.1 * kind[1], kind[1], device)
+        elif kind == "ln_w":
             out[name] = uniform(seed, name, shape, 0.1, 1.0, device)
         elif kind in ("ln_b", "bias"):
             out[name] = uniform(seed, name, shape, 0.02, 0.0, device)

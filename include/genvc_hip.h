@@ -212,6 +212,36 @@ int gvc_dvae_encode(gvc_dvae* ctx, const float* feat, int32_t B, int32_t T, int3
 int gvc_vq_argmin(const float* x, const float* embed, int32_t N, int32_t dim, int32_t n_embed,
                   int32_t* idx, float* work /* N*n_embed floats */, gvc_stream s);
 
+/* ------------------------------------------------------------------------------------------
+ * HiFi-GAN generator.  Replaces layers/hifigan.py:HiFiGAN.forward (:218-233, ResBlock2
+ * :119-157) and, for the latent entry point, the x4 linear interpolation in front of it
+ * (inference/inference_utils.py:81-85, 196-202).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_hifigan gvc_hifigan;
+typedef struct gvc_hifigan_dims {
+    int32_t in_dim;               /* vocoder_config.input_feat_dim (1024) */
+    int32_t up_init_ch;           /* upsample_initial_channel (256) */
+    int32_t n_ups;                /* len(upsample_rates) <= 4 */
+    int32_t up_rates[4];          /* 8, 8, 4 */
+    int32_t up_kernels[4];        /* 16, 16, 8 */
+    int32_t n_kernels;            /* len(resblock_kernel_sizes) <= 4 */
+    int32_t res_kernels[4];       /* 3, 5, 7 */
+    int32_t res_dilations[4][2];  /* ResBlock2: [[1,2],[2,6],[3,12]] */
+    int32_t max_batch, max_frames; /* capacity: input frames AFTER the interpolation */
+} gvc_hifigan_dims;
+int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** out);
+int gvc_hifigan_destroy(gvc_hifigan* ctx);
+/* names of the reference state dict with weight-norm folded (w = g * v / |v|, as remove_weight_norm leaves
+ * them): "conv_pre.weight", "ups.1.bias", "resblocks.4.convs.0.weight", "conv_post.weight", ... */
+int gvc_hifigan_bind_weight(gvc_hifigan* ctx, const char* name, const float* src, int64_t numel, gvc_stream s);
+int gvc_hifigan_missing_weights(gvc_hifigan* ctx);
+/* x [B,in_dim,T] (reference layout) -> wav [B, T * prod(up_rates)] */
+int gvc_hifigan_forward(gvc_hifigan* ctx, const float* x, int32_t B, int32_t T, float* wav, gvc_stream s);
+/* latents [B,n,in_dim] (as yielded by the generation loop) -> F.interpolate(scale, linear) -> wav
+ * [B, n * scale * prod(up_rates)] */
+int gvc_hifigan_forward_latents(gvc_hifigan* ctx, const float* latents, int32_t B, int32_t n, int32_t scale,
+                                float* wav, gvc_stream s);
+
 #ifdef __cplusplus
 }
 #endif

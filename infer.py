@@ -3,8 +3,7 @@
 Flags and defaults are the reference's; added: --seg_len (the reference hard-codes 6.0; the README's
 "1-second chunk" numbers correspond to --seg_len 1.0), --stream_chunk_size, --synthetic (no checkpoint
 ships with the reference: run the same pipeline on deterministic synthetic weights) and --save_tokens.
-Without a vocoder in the checkpoint path (HiFi-GAN is SURVEY row f1, "next") the tool writes the generated
-codec tokens / latents instead of a waveform.
+The waveform is written like the reference does (24 kHz PCM16); --save_tokens also stores the codec tokens/latents.
 """
 import argparse
 
@@ -54,6 +53,6 @@ if __name__ == "__main__":
     if out["wav"] is not None:
         save_wav(args.output_path, out["wav"], config.audio.sample_rate)
     else:
-        print("no vocoder loaded (HiFi-GAN = SURVEY row f1): waveform not written")
+        print("no vocoder in the model: waveform not written")
     if args.save_tokens:
         torch.save(dict(tokens=toks.cpu(), latents=lat.cpu()), args.save_tokens)

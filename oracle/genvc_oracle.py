@@ -359,6 +359,45 @@ def generate(w, dims, cond_latents, codes, sampling, max_new=None, seed=0, stop_
 
 
 # ---------------------------------------------------------------------------
+# row f1: HiFi-GAN generator  (layers/hifigan.py:119-157, 160-233)
+# ---------------------------------------------------------------------------
+
+def _wn(w, name):
+    """fold torch.nn.utils.weight_norm (dim 0): w = g * v / |v|"""
+    v, g = w[name + ".weight_v"], w[name + ".weight_g"]
+    return g * v / v.pow(2).sum(dim=tuple(range(1, v.dim())), keepdim=True).sqrt()
+
+
+def hifigan_forward(w, cfg, x, prefix=""):
+    """x [B,input_feat_dim,T] -> [B,1,T*prod(rates)]"""
+    p = prefix
+    x = F.conv1d(x, _wn(w, p + "conv_pre"), w[p + "conv_pre.bias"], padding=3)
+    nk = len(cfg["resblock_kernel_sizes"])
+    for i, (r, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, _wn(w, f"{p}ups.{i}"), w[f"{p}ups.{i}.bias"], stride=r, padding=(k - r) // 2)
+        xs = None
+        for j, (kk, dil) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
+            r_ = x
+            for q in range(2):                                     # ResBlock2.forward :147-152
+                n = f"{p}resblocks.{i * nk + j}.convs.{q}"
+                xt = F.conv1d(F.leaky_relu(r_, 0.1), _wn(w, n), w[n + ".bias"], dilation=dil[q],
+                              padding=(kk * dil[q] - dil[q]) // 2)
+                r_ = xt + r_
+            xs = r_ if xs is None else xs + r_
+        x = xs / nk
+    x = F.leaky_relu(x)                                            # default slope 0.01 (:230)
+    x = F.conv1d(x, _wn(w, p + "conv_post"), w[p + "conv_post.bias"], padding=3)
+    return torch.tanh(x)
+
+
+def vocode_latents(w, cfg, latents, scale=4.0):
+    """inference_utils.py:81-87: latents [B,n,d] -> interpolate x4 (linear) -> HiFi-GAN"""
+    mel = F.interpolate(latents.transpose(1, 2), scale_factor=[scale], mode="linear")
+    return hifigan_forward(w, cfg, mel)
+
+
+# ---------------------------------------------------------------------------
 # row 13: harness pieces  (inference/inference_utils.py)
 # ---------------------------------------------------------------------------
 

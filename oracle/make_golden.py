@@ -241,6 +241,31 @@ def make_sampler(seed=9):
     print("sampler:", [k for k in out if k.startswith("scores")])
 
 
+@torch.inference_mode()
+def make_hifigan(seed=13):
+    """reference HiFiGAN generator (layers/hifigan.py imports nnAudio at file level: stubbed, only the
+    discriminators use it) on synthetic weight-normed weights."""
+    stub = types.ModuleType("nnAudio"); stub.features = types.ModuleType("nnAudio.features")
+    sys.modules["nnAudio"], sys.modules["nnAudio.features"] = stub, stub.features
+    from layers.hifigan import HiFiGAN
+    out = dict(seed=seed)
+    for tag, c in (("tiny", gcfg.TINY_VOCODER), ("full", gcfg.DEFAULT_VOCODER)):
+        g = HiFiGAN(c["input_feat_dim"], c["upsample_initial_channel"], c["resblock_kernel_sizes"],
+                    c["resblock_dilation_sizes"], c["upsample_rates"], c["upsample_kernel_sizes"], resblock_type="2")
+        w = synth.make_weights(seed, synth.hifigan_weight_spec(c))
+        missing, unexpected = g.load_state_dict(w, strict=True)
+        g.eval()
+        for B, n in ((1, 8), (2, 3), (1, 1)):
+            lat = synth.uniform(seed, f"lat_{B}_{n}", (B, n, c["input_feat_dim"]), 1.0)
+            mel = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[4.0], mode="linear")
+            wav = g(mel)
+            out[f"{tag}_wav_{B}_{n}"] = wav.numpy()
+            out[f"{tag}_mel_{B}_{n}"] = mel.numpy()[:, :8, :]
+    np.savez_compressed(os.path.join(GOLD, "hifigan.npz"), **out)
+    print("hifigan:", {k: v.shape for k, v in out.items() if "wav" in str(k)},
+          "rms", float(np.sqrt((out["full_wav_1_8"] ** 2).mean())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -267,6 +292,8 @@ def main():
         make_dvae(DiscreteVAE)
     if want("sampler"):
         make_sampler()
+    if want("hifigan"):
+        make_hifigan()
 
 
 if __name__ == "__main__":

@@ -85,6 +85,12 @@ def test_harness_streaming_and_offline_agree():
     assert torch.equal(toks_st[keep], torch.cat(nst["codes"]))     # same greedy codes on both paths
     np.testing.assert_allclose(lat_st[keep].cpu().numpy(), nst["latents"][0].cpu().numpy(), atol=1e-4)
     assert st["latency"] is not None and st["rtf"] > 0
+    # waveform: non-streaming = 1024 samples per code; streaming drops 1024 of every vocoder chunk (quirk 8)
+    n_codes = int(torch.cat(nst["codes"]).numel())
+    assert nst["wav"].shape == (n_codes * 1024,) and bool(torch.isfinite(nst["wav"]).all())
+    assert float(nst["wav"].abs().max()) <= 1.0
+    exp = sum(max(t.shape[1] * 1024 - 1024, 0) if t.shape[1] * 1024 > 1024 else 1024 for t in st["tokens"])
+    assert st["wav"].shape[0] == exp and bool(torch.isfinite(st["wav"]).all())
     # batched offline driver (world 1) == per-utterance results
     srcs = [synth.synth_audio(10 + i, "src", 32000) for i in range(3)]
     allt = convert_offline(m, srcs, ref, seg_len=1.0, micro_batch=2, rank=0, world=1, top_k=1)

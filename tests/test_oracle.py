@@ -135,3 +135,15 @@ def test_segmentation_and_chunks():
     c2, ov2 = O.handle_chunks(w1 + 1.0, ov)
     assert c2.shape[0] == 7168
     assert abs(float(c2[0]) - float(ov[0])) < 1e-6                            # fade starts at the old tail
+
+
+def test_hifigan_vs_reference(gold):
+    g = gold("hifigan")
+    seed = int(g["seed"])
+    for tag, c in (("tiny", gcfg.TINY_VOCODER), ("full", gcfg.DEFAULT_VOCODER)):
+        w = synth.make_weights(seed, synth.hifigan_weight_spec(c))
+        for B, n in ((1, 8), (2, 3), (1, 1)):
+            lat = synth.uniform(seed, f"lat_{B}_{n}", (B, n, c["input_feat_dim"]), 1.0)
+            wav = O.vocode_latents(w, c, lat)
+            assert wav.shape == (B, 1, n * 4 * 256)
+            np.testing.assert_allclose(wav.numpy(), g[f"{tag}_wav_{B}_{n}"], atol=2e-5)
