@@ -369,8 +369,10 @@ static int gemv_geom(const gvc_gpt* c, int N, int K, GemvGeom* g) {
     g->ksplit = K / (g->NI * 256);
     GVC_REQUIRE(g->ksplit * g->NI * 256 == K && g->ksplit <= 8, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
     const int items = N * g->ksplit;
-    int wpb = cdiv(items, c->n_cu);
-    if (wpb > 12) wpb = cdiv(items, 2 * c->n_cu);
+    static const int wpb_split = getenv("GVC_WPB_SPLIT") ? atoi(getenv("GVC_WPB_SPLIT")) : 12;
+    static const int blocks_per_cu = getenv("GVC_BLOCKS_PER_CU") ? atoi(getenv("GVC_BLOCKS_PER_CU")) : 1;
+    int wpb = cdiv(items, blocks_per_cu * c->n_cu);
+    if (wpb > wpb_split) wpb = cdiv(items, 2 * blocks_per_cu * c->n_cu);
     if (wpb < 4) wpb = 4;
     wpb = cdiv(wpb, g->ksplit) * g->ksplit;
     if (wpb > 15) wpb = 15 / g->ksplit * g->ksplit;
