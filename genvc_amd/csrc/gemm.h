@@ -10,6 +10,14 @@
 
 namespace gvc {
 
+// "FM16" fragment-major layout of an [M][K] matrix (M, K multiples of 16): each (16 rows x 16 k) block is stored as
+// the 64 float4 a wave feeds to v_mfma_f32_16x16x4_f32 -- slot (m%16) + 16*((k%16)/4) holds k%16/4*4..+3 of row m -- so one
+// fragment load is 1 KiB contiguous (a row-major fragment load touches 16 cache lines per quarter-wave and is
+// tag-lookup bound in the texture path: 15 us instead of 4 for the prefill GEMMs).
+__host__ __device__ __forceinline__ size_t fm16_index(int m, int k, int K) {
+    return ((size_t)(m >> 4) * (K >> 4) + (k >> 4)) * 256 + (size_t)((((m & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3));
+}
+
 enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_RELU = 2 };
 enum GemmAAct { AACT_NONE = 0, AACT_LRELU = 1 };   // activation applied to A while it is staged (HiFi-GAN)
 
@@ -22,6 +30,7 @@ struct GemmEpi {
     const float* resid2;     // second residual with the layout of `resid` (HiFi-GAN resblock sum), or null
     float out_scale;         // 0 = none; otherwise the stored value is multiplied by it
     // GPT QKV scatter (prefill): n < d -> q[m][n]; else K/V cache rows
+    int c_fm16;              // 1 -> C is written in FM16 layout (row length N)
     int qkv;                 // 1 -> scatter mode, C is the q buffer [M][d]
     int d, n_head, head_dim, max_seq, T;
     float* kcache; float* vcache;
@@ -64,6 +73,7 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, 
     if (e.resid) v += e.resid[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
     if (e.resid2) v += e.resid2[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
     if (e.out_scale != 0.f) v *= e.out_scale;
+    if (e.c_fm16) { G.C[fm16_index(m, n, G.N)] = v; return; }
     G.C[batch * G.c_batch_stride + (size_t)m * G.ldc + n] = v;
 }
 
@@ -71,6 +81,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G);
 __global__ void k_splitk_epilogue(const GemmArgs G);
+
+// Skinny GEMM for M <= 128 rows (streaming prefill): one workgroup per 16 weight rows, its 4 or 8 waves split K and
+// combine through LDS; BOTH operands are FM16 (G.A [M][K], G.Wt [N][K]) and go straight from global/L2 into MFMA
+// fragments (v_mfma_f32_16x16x4_f32), 1 KiB per load instruction.
+// G.SK > 1: the K range is also split over blockIdx.y and RAW partial sums go to G.work[sk][M][N] (the consumer,
+// k_ln_sum_rows, adds them together with bias and residual: no separate split-K epilogue launch).
+int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s);
+// x[row] += bias + sum_s part[s][row];  a[row] = LayerNorm(x[row]) (skipped when ln_w is null); one workgroup per
+// row (grid = rows, 256 threads), d <= 4096, SK <= 8
+__global__ void k_ln_sum_rows(float* x, float* a, const float* part, int SK, const float* bias, int rows, int d,
+                              const float* ln_w, const float* ln_b, int a_fm16);
+// row-major [N][K] -> FM16
+__global__ void k_to_fm16(const float* src, float* dst, int N, int K);
 
 // chooses the split-K factor from the shape; `work_cap` = capacity of G.work in floats
 int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s);

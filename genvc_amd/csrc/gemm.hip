@@ -130,4 +130,160 @@ int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
     return GVC_OK;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) float red_raw[];     // [NW][MT][256]
+    float (*red)[MT][256] = reinterpret_cast<float (*)[MT][256]>(red_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kslice = G.K / G.SK;                 // per workgroup
+    const int kw = kslice / NW;                    // per wave, multiple of 16
+    (void)r; (void)g;
+    const int kb16 = (blockIdx.y * kslice + wave * kw) >> 4;       // first 16-wide k block of this wave
+    const int K16 = G.K >> 4;
+    const float* wp = G.Wt + ((size_t)(n0 >> 4) * K16 + kb16) * 256 + lane * 4;      // FM16 operands: a k step = +256 floats
+    const float* ap[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ap[t] = G.A + ((size_t)t * K16 + kb16) * 256 + lane * 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+    // all fragment loads of a batch are issued before the first MFMA; a batch is sized to ~32 float4 per lane
+    // (the whole K range of a wave for the GenVC shapes), so a wave pays one memory round trip
+    constexpr int U = 32 / (1 + MT) >= 8 ? 8 : (32 / (1 + MT) >= 4 ? 4 : 2);
+    for (int ks = 0; ks < kw; ks += 16 * U) {
+        float4 w4[U], a4[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = ks + 16 * u;
+            const bool kin = k < kw;                   // rows past M hold stale data: their results are never stored
+            w4[u] = kin ? *reinterpret_cast<const float4*>(wp + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                a4[u][t] = kin ? *reinterpret_cast<const float4*>(ap[t] + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].x, w4[u].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].y, w4[u].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].z, w4[u].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].w, w4[u].w, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][t][q * 64 + lane] = acc[t][q];
+    __syncthreads();
+    // thread (q, lane) finishes element row 16t + 4*(lane>>4) + q, column n0 + (lane & 15); tiles are shared out
+    // over the workgroup's thread quads
+    const int q = (tid >> 6) & 3;
+    const int n = n0 + (lane & 15);
+    for (int t = tid >> 8; t < MT; t += NW / 4) {
+        const int m = 16 * t + 4 * (lane >> 4) + q;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][t][q * 64 + lane];
+        if (m < G.M) {
+            if (G.SK > 1) G.work[((size_t)blockIdx.y * G.M + m) * G.N + n] = v;
+            else gemm_store(G, 0, m, n, v);
+        }
+    }
+}
+
+// one workgroup (256 threads) per row: every operand of the row is requested in one round trip
+__global__ void k_to_fm16(const float* src, float* dst, int N, int K) {
+    const size_t n4 = (size_t)N * K / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+        *reinterpret_cast<float4*>(dst + fm16_index(n, k, K)) = *reinterpret_cast<const float4*>(src + (size_t)n * K + k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ln_sum_rows(float* x, float* a, const float* part, int SK, const float* bias,
+                                                     int rows, int d, const float* ln_w, const float* ln_b, int a_fm16) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float* xr = x + (size_t)row * d;
+    const size_t pstride = (size_t)rows * d;
+    constexpr int MAXV = 4;                          // d <= 4096
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int k = (i * 256 + tid) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < d) {
+            v[i] = *reinterpret_cast<const float4*>(xr + k);
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + k);
+            float4 p4[8];
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx)
+                p4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + sidx * pstride + (size_t)row * d + k)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[i].x += b4.x; v[i].y += b4.y; v[i].z += b4.z; v[i].w += b4.w;
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx) { v[i].x += p4[sidx].x; v[i].y += p4[sidx].y; v[i].z += p4[sidx].z; v[i].w += p4[sidx].w; }
+            *reinterpret_cast<float4*>(xr + k) = v[i];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    if (!ln_w) return;
+    const float inv_d = 1.0f / (float)d;
+    const float mean = block4_sum(s, red) * inv_d;
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int k = (i * 256 + tid) * 4;
+        if (k < d) {
+            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+            qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block4_sum(qv, red) * inv_d + 1e-5f);
+    float* ar = a + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int k = (i * 256 + tid) * 4;
+        if (k < d) {
+            const float4 gw = *reinterpret_cast<const float4*>(ln_w + k);
+            const float4 gb = *reinterpret_cast<const float4*>(ln_b + k);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gw.x + gb.x; o.y = (v[i].y - mean) * rstd * gw.y + gb.y;
+            o.z = (v[i].z - mean) * rstd * gw.z + gb.z; o.w = (v[i].w - mean) * rstd * gw.w + gb.w;
+            if (a_fm16) *reinterpret_cast<float4*>(a + fm16_index(row, k, d)) = o;
+            else *reinterpret_cast<float4*>(ar + k) = o;
+        }
+    }
+}
+
+int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
+    const int MT = cdiv(G.M, 16);
+    GVC_REQUIRE(MT >= 1 && MT <= 8 && G.N % 16 == 0 && SK >= 1 && SK <= 8 && G.K % (SK * 64) == 0, GVC_ERR_ARG,
+                "skinny gemm: unsupported shape M=%d N=%d K=%d SK=%d", G.M, G.N, G.K, SK);
+    GVC_REQUIRE(SK == 1 || (G.work && (long long)SK * G.M * G.N <= work_cap), GVC_ERR_ARG, "skinny gemm: work buffer too small");
+    GVC_REQUIRE(G.conv_cin == 0 && G.a_act == 0 && G.K % 16 == 0, GVC_ERR_ARG, "skinny gemm: FM16 operands only");
+    G.SK = SK;
+    dim3 grid(G.N / 16, SK);
+    const bool w8 = (G.K / SK) % 128 == 0;           // 8 waves when every wave still gets whole 16-wide k steps
+    const size_t lds = (size_t)(w8 ? 8 : 4) * MT * 256 * sizeof(float);
+#define GVC_SKINNY(mt)                                                                               \
+    case mt:                                                                                         \
+        if (w8) hipLaunchKernelGGL((k_gemm_skinny<mt, 8>), grid, dim3(512), lds, s, G);              \
+        else hipLaunchKernelGGL((k_gemm_skinny<mt, 4>), grid, dim3(256), lds, s, G);                 \
+        break;
+    switch (MT) { GVC_SKINNY(1) GVC_SKINNY(2) GVC_SKINNY(3) GVC_SKINNY(4) GVC_SKINNY(5) GVC_SKINNY(6) GVC_SKINNY(7) GVC_SKINNY(8) }
+#undef GVC_SKINNY
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
 }  // namespace gvc

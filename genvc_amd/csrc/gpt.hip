@@ -17,7 +17,7 @@ namespace gvc {
 // row kernels
 // ---------------------------------------------------------------------------------------------
 __global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const float* w1, const float* b1,
-                          const float* w2, const float* b2) {
+                          const float* w2, const float* b2, int dst_fm16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -47,7 +47,8 @@ __global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const f
             const float4 c = *reinterpret_cast<const float4*>(gb + k);
             v.x = (v.x - mean) * rstd * g.x + c.x; v.y = (v.y - mean) * rstd * g.y + c.y;
             v.z = (v.z - mean) * rstd * g.z + c.z; v.w = (v.w - mean) * rstd * g.w + c.w;
-            *reinterpret_cast<float4*>(y + k) = v;
+            if (dst_fm16 && !w2) *reinterpret_cast<float4*>(dst + fm16_index(row, k, d)) = v;
+            else *reinterpret_cast<float4*>(y + k) = v;
         }
     }
 }
@@ -150,6 +151,7 @@ using namespace gvc;
 // ---------------------------------------------------------------------------------------------
 struct GptLayer {
     float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *p2_w, *p2_b;
+    float *qkv_f = nullptr, *proj_f = nullptr, *fc_f = nullptr, *p2_f = nullptr;   // FM16 copies for the skinny prefill GEMM
 };
 
 struct gvc_gpt {
@@ -157,6 +159,7 @@ struct gvc_gpt {
     int hd = 0, n_cu = 256;
     int prefetch = 0;                 // experimental L2 warm-up of the next launch's weights (GVC_PREFETCH=1)
     float* wbase = nullptr;           // one allocation for all weights
+    float* wfm = nullptr;             // FM16 copies of the four per-layer matrices (prefill path)
     float *mel_emb, *mel_pos, *text_emb, *text_pos, *lnf_w, *lnf_b, *fn_w, *fn_b, *head_w, *head_b;
     std::vector<GptLayer> layers;
     std::map<std::string, int> bound;  // name -> 1 once bound
@@ -167,6 +170,7 @@ struct gvc_gpt {
     long long work_cap = 0;
     float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
     int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
+    int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
     int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step
     GptState st;
@@ -235,6 +239,14 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
         ly.fc_w = take(4 * d * d); ly.fc_b = take(4 * d); ly.p2_w = take(4 * d * d); ly.p2_b = take(d);
     }
     c->n_expected = 10 + 12 * (int)L;
+    if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
+    if (c->skinny_prefill) {
+        if ((rc = alloc_f(&c->wfm, L * 12 * d * d))) { gvc_gpt_destroy(c); return rc; }
+        float* f = c->wfm;
+        for (auto& ly : c->layers) {
+            ly.qkv_f = f; f += 3 * d * d; ly.proj_f = f; f += d * d; ly.fc_f = f; f += 4 * d * d; ly.p2_f = f; f += 4 * d * d;
+        }
+    }
 
     c->kv_layer_stride = (size_t)D.max_slots * D.n_head * D.max_seq * hd;
     const size_t rows = D.max_rows;
@@ -283,7 +295,7 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->sched) hipFree(c->sched);
     if (c->prog) hipFree(c->prog);
-    for (void* p : {(void*)c->wbase, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
+    for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
         if (p) hipFree(p);
@@ -299,11 +311,16 @@ static int copy_w(float* dst, const float* src, int64_t numel, int64_t expect, c
 }
 
 // HF Conv1D weight [K][N] -> row-per-output [N][K]
-static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N, const char* name, hipStream_t s) {
+static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N, const char* name, hipStream_t s,
+                       float* dst_fm16 = nullptr) {
     GVC_REQUIRE(numel == (int64_t)K * N, GVC_ERR_ARG, "%s: expected %lld elements, got %lld", name,
                 (long long)K * N, (long long)numel);
     hipLaunchKernelGGL(k_transpose, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(32, 8), 0, s, src, dst, K, N);
     GVC_LAUNCH_CHECK();
+    if (dst_fm16) {      // second copy in MFMA fragment order for the skinny prefill GEMM
+        hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, dst, dst_fm16, N, K);
+        GVC_LAUNCH_CHECK();
+    }
     return GVC_OK;
 }
 
@@ -333,15 +350,15 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
         GptLayer& ly = c->layers[li];
         if (rest == "ln_1.weight") rc = copy_w(ly.ln1_w, src, numel, d, name, s);
         else if (rest == "ln_1.bias") rc = copy_w(ly.ln1_b, src, numel, d, name, s);
-        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s);
+        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f);
         else if (rest == "attn.c_attn.bias") rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s);
-        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s);
+        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f);
         else if (rest == "attn.c_proj.bias") rc = copy_w(ly.proj_b, src, numel, d, name, s);
         else if (rest == "ln_2.weight") rc = copy_w(ly.ln2_w, src, numel, d, name, s);
         else if (rest == "ln_2.bias") rc = copy_w(ly.ln2_b, src, numel, d, name, s);
-        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s);
+        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f);
         else if (rest == "mlp.c_fc.bias") rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s);
-        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s);
+        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f);
         else if (rest == "mlp.c_proj.bias") rc = copy_w(ly.p2_b, src, numel, d, name, s);
         else known = false;   // attn.bias / attn.masked_bias buffers of 4.33-era checkpoints
     } else {
@@ -610,45 +627,72 @@ extern "C" int gvc_gpt_prefix_embeddings(gvc_gpt* c, const float* cond, int32_t 
     return GVC_OK;
 }
 
-// block stack over B*T rows already in c->x; K/V of every row go to the slots' cache (positions 0..T-1)
+// block stack over B*T rows already in c->x; K/V of every row go to the slots' cache (positions 0..T-1).
+// rows <= 128 (a streaming prefill): skinny MFMA GEMMs; the N = d projections are K-split over 4 workgroup
+// rows and their raw partial sums are folded into the NEXT LayerNorm launch (k_ln_sum_rows), so a layer is
+// 7 launches.  Larger row counts (batched offline prefill, latent re-pass) use the tiled GEMM.
 static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s) {
     const int d = c->dm.d_model, rows = B * T;
     int rc;
+    const bool skinny = c->skinny_prefill && c->wfm && rows <= 128 && d % 256 == 0 && (long long)4 * rows * d <= c->work_cap / 2;
+    const int SKP = 4;
+    float* part_proj = c->work;                                    // [SKP][rows][d]
+    float* part_p2 = c->work + c->work_cap / 2;                    // [SKP][rows][d]
+    auto ln = [&](const float* w, const float* b) {
+        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, w, b, (const float*)nullptr,
+                           (const float*)nullptr, skinny ? 1 : 0);
+    };
+    auto ln_sum = [&](const float* part, const float* bias, const float* w, const float* b) {
+        hipLaunchKernelGGL(k_ln_sum_rows, dim3(rows), dim3(256), 0, s, c->x, c->a, part, SKP, bias, rows, d, w, b, 1);
+    };
     for (int l = 0; l < c->dm.n_layer; ++l) {
         const GptLayer& ly = c->layers[l];
-        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, ly.ln1_w, ly.ln1_b,
-                           (const float*)nullptr, (const float*)nullptr);
+        if (skinny && l > 0) ln_sum(part_p2, c->layers[l - 1].p2_b, ly.ln1_w, ly.ln1_b);
+        else ln(ly.ln1_w, ly.ln1_b);
         GVC_LAUNCH_CHECK();
         GemmArgs G;
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
         G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots;
         G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
         G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
-        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         AttnArgs At = gpt_attn_args(c, l, slots);
-        At.q = c->q; At.T = T; At.base_len = nullptr; At.out = c->a; At.out_stride = d;
+        At.q = c->q; At.T = T; At.base_len = nullptr; At.out = c->a; At.out_stride = d; At.out_fm16 = skinny ? 1 : 0;
         if ((rc = launch_attention(c, At, 1, rows, true, s))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = ly.proj_w; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
-        G.work = c->work; G.e.bias = ly.proj_b; G.e.resid = c->x; G.e.ldr = d;
-        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
-
-        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, ly.ln2_w, ly.ln2_b,
-                           (const float*)nullptr, (const float*)nullptr);
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.proj_f : ly.proj_w; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
+        if (skinny) {
+            G.work = part_proj;
+            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
+            ln_sum(part_proj, ly.proj_b, ly.ln2_w, ly.ln2_b);
+        } else {
+            G.work = c->work; G.e.bias = ly.proj_b; G.e.resid = c->x; G.e.ldr = d;
+            if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+            ln(ly.ln2_w, ly.ln2_b);
+        }
         GVC_LAUNCH_CHECK();
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = ly.fc_w; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
-        G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW;
-        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.fc_f : ly.fc_w; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+        G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = skinny ? 1 : 0;
+        if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->h; G.lda = 4 * d; G.Wt = ly.p2_w; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
-        G.work = c->work; G.e.bias = ly.p2_b; G.e.resid = c->x; G.e.ldr = d;
-        if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        G.A = c->h; G.lda = 4 * d; G.Wt = skinny ? ly.p2_f : ly.p2_w; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
+        if (skinny) {
+            G.work = part_p2;
+            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
+        } else {
+            G.work = c->work; G.e.bias = ly.p2_b; G.e.resid = c->x; G.e.ldr = d;
+            if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        }
+    }
+    if (skinny) {       // fold the last layer's mlp partials into the residual stream
+        ln_sum(part_p2, c->layers[c->dm.n_layer - 1].p2_b, nullptr, nullptr);
+        GVC_LAUNCH_CHECK();
     }
     return GVC_OK;
 }
@@ -697,7 +741,7 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
     GVC_LAUNCH_CHECK();
     if ((rc = run_rows(c, slots, B, T, s))) return rc;
     hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(B * T, 4)), dim3(256), 0, s, c->x, c->a, B * T, d, c->lnf_w, c->lnf_b,
-                       c->fn_w, c->fn_b);
+                       c->fn_w, c->fn_b, 0);
     GVC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_gather_rows, dim3(B * n), dim3(256), 0, s, c->a, out, B, T, P, n, d);
     GVC_LAUNCH_CHECK();

@@ -434,6 +434,7 @@ struct AttnArgs {
     int out_stride;
     Prefetch pf;               // next launch's weights, fetched by the 5th wave (blockDim 320)
     int32_t* prog;             // null, or the step's progress counter (++ when this launch starts)
+    int out_fm16;              // DIRECT: write `out` in the FM16 layout of gemm.h (row length out_stride)
 };
 
 template <int HD, bool DIRECT>
@@ -526,6 +527,10 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
             }
         }
         if constexpr (DIRECT) {
+            if (A.out_fm16) {
+                const int m = row, k = h * HD + j, K16 = A.out_stride >> 4;
+                A.out[((size_t)(m >> 4) * K16 + (k >> 4)) * 256 + ((((m & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3))] = acc / L;
+            } else
             A.out[(size_t)row * A.out_stride + h * HD + j] = acc / L;
         } else {
             float* pp = A.out + (((size_t)row * nhead + h) * nchunk + chunk) * (HD + 4);
@@ -696,7 +701,7 @@ static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (optionally twice: ln_f then final_norm) of rows src -> dst
 __global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const float* w1, const float* b1,
-                          const float* w2, const float* b2);
+                          const float* w2, const float* b2, int dst_fm16);
 // build GPT input rows: t < P -> prefix_emb[b][t]; else mel_embedding[tok] + mel_pos[t - P]
 //   tok: t == P -> start_tok; 1 <= t-P <= n -> codes[b][t-P-1]; beyond -> stop_tok
 __global__ void k_embed_rows(float* x, const float* prefix_emb, int B, int T, int P, int d, const float* mel_emb,
