@@ -9,6 +9,8 @@
 //   * leaky_relu on the conv inputs is applied while the A tile is staged; bias, the residual add, the running sum over
 //     the three ResBlocks and the final 1/3 are fused in the epilogue.
 // conv_post (Cout = 1) + tanh is a small dedicated kernel.  Weight-norm (weight_g, weight_v) is folded by the loader.
+#include <stdlib.h>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -128,6 +130,11 @@ struct gvc_hifigan {
     long long work_cap = 0;
     std::vector<void*> allocs;
     int cur_T0 = -1, cur_B = -1;
+    // the GEMM chain between the input staging and conv_post only touches context buffers: it is captured once per
+    // (B, frames) and replayed (about 30 launches of a few microseconds each are host-bound when launched eagerly)
+    std::map<long long, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
+    int use_graph = 1;
 };
 
 static int halloc(gvc_hifigan* c, float** p, size_t n) {
@@ -192,12 +199,16 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     if (!rc) rc = halloc(c, &c->work, (size_t)c->work_cap);
     c->n_expected = 2 * (2 + D.n_ups + 2 * D.n_ups * D.n_kernels);
     if (rc) { gvc_hifigan_destroy(c); return rc; }
+    if (getenv("GVC_VOCODER_GRAPH")) c->use_graph = atoi(getenv("GVC_VOCODER_GRAPH"));
+    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     *out = c;
     return GVC_OK;
 }
 
 extern "C" int gvc_hifigan_destroy(gvc_hifigan* c) {
     if (!c) return GVC_OK;
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) hipFree(p);
     delete c;
     return GVC_OK;
@@ -281,7 +292,8 @@ static int hf_conv(gvc_hifigan* c, const HfConv& w, const float* src, float* dst
     return launch_gemm_cap(G, B, c->work_cap, s);
 }
 
-static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
+// conv_pre .. last ResBlock sum; returns the final activation buffer and its length
+static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, const float** x_out, int* T_out) {
     int rc;
     const gvc_hifigan_dims& D = c->dm;
     if ((rc = hf_conv(c, c->pre, c->x0, c->x1, T0, B, 0.f, nullptr, nullptr, 0.f, s))) return rc;
@@ -313,6 +325,40 @@ static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
             prev = dst;
         }
         x = prev;
+    }
+    *x_out = x;
+    *T_out = T;
+    return GVC_OK;
+}
+
+static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
+    int rc;
+    const float* x = nullptr;
+    int T = 0;
+    if (!c->use_graph) {
+        if ((rc = hf_body(c, B, T0, s, &x, &T))) return rc;
+    } else {
+        const long long key = ((long long)B << 32) | (unsigned)T0;
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+            rc = hf_body(c, B, T0, c->cap_stream, &x, &T);
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+            if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+            GVC_CHECK_HIP(e);
+            hipGraphExec_t ge;
+            e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            GVC_CHECK_HIP(e);
+            it = c->graphs.emplace(key, ge).first;
+        }
+        GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
+        // geometry of the final activation (what hf_body would have returned)
+        T = T0;
+        for (const HfUp& u : c->ups) T *= u.s;
+        const int nk = c->dm.n_kernels, last = (int)c->ups.size() - 1;
+        x = ((nk - 1) & 1) ? c->S1[last] : c->S0[last];
     }
     const HfConv& p = c->post;
     hipLaunchKernelGGL(k_conv_post_tanh, dim3(cdiv(T, 256), B), dim3(256), p.k * p.Ci * sizeof(float), s, x, p.w, p.b, wav, T,
