@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(SampleCall cv, const Sa
             double total = 0.0;
             for (int i = 0; i < V; ++i)
                 if (sc[i] >= thresh) total += (double)expf(sc[i] - mx);
-            const double target = (double)rng_uniform(C.p.seed, (uint64_t)step, (uint64_t)b) * total;
+            // the RNG counter is the position of the step in the whole run (i0 + step), not in this call
+            const double target = (double)rng_uniform(C.p.seed, (uint64_t)(C.i0 + step), (uint64_t)b) * total;
             double acc = 0.0;
             int pick = -1, lastk = 0;
             for (int i = 0; i < V; ++i) {

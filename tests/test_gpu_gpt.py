@@ -194,3 +194,68 @@ def test_missing_weights_fail_loudly():
     slots = torch.zeros(1, dtype=torch.int32, device="cuda")
     with pytest.raises(GenvcHipError):
         eng.decode_step(slots, slots)
+
+
+def test_batch5_and_long_context_teacher_forced_vs_oracle():
+    """edge cases: a batch that pads to the 8-stream kernel, mel positions up to the 602 cap, a context long
+    enough for the split-key (unfused) attention path; logits teacher-forced against the oracle."""
+    from oracle import genvc_oracle as O
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3)
+    wc = cpu_weights(w)
+    dev = "cuda"
+    B, Tc = 5, 40
+    cond = synth.uniform(31, "cond_latents", (B, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(31, "content_codes", (B, Tc), 256)
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    slots = torch.tensor([7, 1, 3, 0, 5], device=dev, dtype=torch.int32)
+    lg, lat = eng.prefill(slots, prefix)
+    pe, _ = O.compute_embeddings(wc, dims, cond, codes)
+    z, logits, cache = O.gpt_prefill(wc, dims, pe)
+    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4)
+    n = dims["max_gen_mel_tokens"]                      # 602 decode inputs -> mel_pos 1..602, cache up to 676 rows
+    toks = synth.integers(32, "toks", (B, n), 1024)
+    check_at = {1, 2, 100, 300, 601, 602}
+    for j in range(1, n + 1):
+        lg, lat = eng.decode_step(slots, toks[:, j - 1].to(dev).int().contiguous())
+        z, logits, cache = O.gpt_decode_step(wc, dims, cache, toks[:, j - 1], j)
+        if j in check_at:
+            np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=2e-4)
+            np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=2e-4)
+
+
+def test_maximum_prefix_uses_the_tiled_gemm_path():
+    """402 content codes (the model's maximum) -> 437 prefill rows: beyond the skinny-GEMM limit of 128 rows"""
+    from oracle import genvc_oracle as O
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3)
+    wc = cpu_weights(w)
+    dev = "cuda"
+    Tc = gcfg.TINY_MODEL_ARGS["gpt_max_text_tokens"]
+    cond = synth.uniform(33, "cond_latents", (1, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(33, "content_codes", (1, Tc), 256)
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    assert prefix.shape[1] == 32 + Tc + 2
+    lg, lat = eng.prefill(torch.zeros(1, device=dev, dtype=torch.int32), prefix)
+    pe, _ = O.compute_embeddings(wc, dims, cond, codes)
+    np.testing.assert_allclose(prefix.cpu().numpy(), pe.numpy(), atol=1e-6)
+    z, logits, _ = O.gpt_prefill(wc, dims, pe)
+    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4)
+    np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=1e-4)
+
+
+def test_topk50_sampling_loop_matches_oracle():
+    """BASELINE configs[4] samples with top_k=50: the graph-replayed loop and the oracle draw from the same
+    counter RNG, so the sampled ids agree step by step."""
+    from oracle import genvc_oracle as O
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3)
+    wc = cpu_weights(w)
+    samp = dict(gcfg.DEFAULT_SAMPLING, top_k=50)
+    cond = synth.uniform(41, "cond_latents", (2, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(41, "content_codes", (2, 13), 256)
+    n = 24
+    _, toks, lats = run_generate(eng, dims, cond, codes, n, sampling=samp, seed=1234)
+    ref_t, ref_l, _ = O.generate(wc, dims, cond, codes, samp, max_new=n, seed=1234, stop_on_eos=False)
+    m = min(toks.shape[1], ref_t.shape[1])
+    agree = (toks[:, :m].long() == ref_t[:, :m])
+    # a draw that lands within float rounding of a CDF boundary may differ; everything before it must agree
+    first_bad = [int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else m for b in range(2)]
+    assert min(first_bad) >= m - 2, (toks, ref_t)
