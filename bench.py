@@ -111,7 +111,7 @@ class Workload:
         return self.toks
 
 
-def cpu_baseline(wl, budget_s=20.0):
+def cpu_baseline(wl, budget_s=10.0):
     """The oracle (port) on the host cores, one 1 s chunk at a time (DVAE+VQ, prefix, prefill, 24 steps)."""
     from oracle import genvc_oracle as O
     m = wl.model

@@ -126,8 +126,9 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(SampleCall cv, const Sa
         tok = s_tok;
     }
 
-    // finished rows emit the pad (= eos) token (stream_generator.py:861-864, 872-874)
-    if (C.finished[b]) tok = C.p.eos_token;
+    // finished rows emit the pad (= eos) token (stream_generator.py:861-864, 872-874); a row whose ids buffer is
+    // full is finished too (the caller sized it for the whole run: nothing past it can be accounted for)
+    if (C.finished[b] || len >= C.ids_stride) tok = C.p.eos_token;
     __syncthreads();
     if (tid == 0) {
         if (len < C.ids_stride) { ids[len] = tok; C.ids_len[b] = len + 1; }
