@@ -14,7 +14,7 @@ c_f32p = C.POINTER(C.c_float)
 
 class GptDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layer", "d_model", "n_head", "vocab", "max_mel_pos", "max_text_pos",
-                                         "n_text", "max_seq", "max_slots", "max_rows")]
+                                         "n_text", "max_seq", "max_slots", "max_rows", "weight_dtype")]
 
 
 class SampleParams(C.Structure):

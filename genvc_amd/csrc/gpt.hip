@@ -116,6 +116,15 @@ __global__ void k_gather_rows(const float* src, float* dst, int B, int T, int of
         *reinterpret_cast<float4*>(o + k) = *reinterpret_cast<const float4*>(s + k);
 }
 
+__global__ void k_round_bf16(float* w, unsigned short* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned u = __float_as_uint(w[i]);
+        const unsigned r = u + 0x7fffu + ((u >> 16) & 1u);            // round to nearest even (finite inputs)
+        out[i] = (unsigned short)(r >> 16);
+        w[i] = __uint_as_float(r & 0xffff0000u);
+    }
+}
+
 __global__ void k_transpose(const float* src, float* dst, int K, int N) {
     __shared__ float tile[32][33];
     const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -152,6 +161,7 @@ using namespace gvc;
 struct GptLayer {
     float *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc_w, *fc_b, *p2_w, *p2_b;
     float *qkv_f = nullptr, *proj_f = nullptr, *fc_f = nullptr, *p2_f = nullptr;   // FM16 copies for the skinny prefill GEMM
+    unsigned short *qkv_h = nullptr, *proj_h = nullptr, *fc_h = nullptr, *p2_h = nullptr;   // bf16 copies (bf16-weights contexts)
 };
 
 struct gvc_gpt {
@@ -160,6 +170,9 @@ struct gvc_gpt {
     int prefetch = 0;                 // experimental L2 warm-up of the next launch's weights (GVC_PREFETCH=1)
     float* wbase = nullptr;           // one allocation for all weights
     float* wfm = nullptr;             // FM16 copies of the four per-layer matrices (prefill path)
+    unsigned short* wh = nullptr;     // bf16 copies of the streamed matrices (weight_dtype = 1)
+    unsigned short* head_h = nullptr;
+    int bf16 = 0;
     float *mel_emb, *mel_pos, *text_emb, *text_pos, *lnf_w, *lnf_b, *fn_w, *fn_b, *head_w, *head_b;
     std::vector<GptLayer> layers;
     std::map<std::string, int> bound;  // name -> 1 once bound
@@ -240,6 +253,16 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     }
     c->n_expected = 10 + 12 * (int)L;
     if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
+    c->bf16 = D.weight_dtype == 1;
+    GVC_REQUIRE(D.weight_dtype == 0 || D.weight_dtype == 1, GVC_ERR_ARG, "weight_dtype must be 0 (fp32) or 1 (bf16)");
+    if (c->bf16) {
+        GVC_CHECK_HIP(hipMalloc((void**)&c->wh, (L * 12 * d * d + V * d + 64) * sizeof(unsigned short)));
+        unsigned short* hq = c->wh;
+        for (auto& ly : c->layers) {
+            ly.qkv_h = hq; hq += 3 * d * d; ly.proj_h = hq; hq += d * d; ly.fc_h = hq; hq += 4 * d * d; ly.p2_h = hq; hq += 4 * d * d;
+        }
+        c->head_h = hq;
+    }
     if (c->skinny_prefill) {
         if ((rc = alloc_f(&c->wfm, L * 12 * d * d))) { gvc_gpt_destroy(c); return rc; }
         float* f = c->wfm;
@@ -295,7 +318,7 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->sched) hipFree(c->sched);
     if (c->prog) hipFree(c->prog);
-    for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
+    for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
         if (p) hipFree(p);
@@ -312,11 +335,15 @@ static int copy_w(float* dst, const float* src, int64_t numel, int64_t expect, c
 
 // HF Conv1D weight [K][N] -> row-per-output [N][K]
 static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N, const char* name, hipStream_t s,
-                       float* dst_fm16 = nullptr) {
+                       float* dst_fm16 = nullptr, unsigned short* dst_bf16 = nullptr) {
     GVC_REQUIRE(numel == (int64_t)K * N, GVC_ERR_ARG, "%s: expected %lld elements, got %lld", name,
                 (long long)K * N, (long long)numel);
     hipLaunchKernelGGL(k_transpose, dim3(cdiv(N, 32), cdiv(K, 32)), dim3(32, 8), 0, s, src, dst, K, N);
     GVC_LAUNCH_CHECK();
+    if (dst_bf16) {      // bf16-weights context: every path uses the SAME rounded values (fp32 copy rounded in place)
+        hipLaunchKernelGGL(k_round_bf16, dim3(1024), dim3(256), 0, s, dst, dst_bf16, (size_t)K * N);
+        GVC_LAUNCH_CHECK();
+    }
     if (dst_fm16) {      // second copy in MFMA fragment order for the skinny prefill GEMM
         hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, dst, dst_fm16, N, K);
         GVC_LAUNCH_CHECK();
@@ -339,7 +366,13 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
     else if (n == "gpt.ln_f.bias") rc = copy_w(c->lnf_b, src, numel, d, name, s);
     else if (n == "final_norm.weight") rc = copy_w(c->fn_w, src, numel, d, name, s);
     else if (n == "final_norm.bias") rc = copy_w(c->fn_b, src, numel, d, name, s);
-    else if (n == "mel_head.weight") rc = copy_w(c->head_w, src, numel, V * d, name, s);
+    else if (n == "mel_head.weight") {
+        rc = copy_w(c->head_w, src, numel, V * d, name, s);
+        if (rc == GVC_OK && c->bf16) {
+            hipLaunchKernelGGL(k_round_bf16, dim3(1024), dim3(256), 0, s, c->head_w, c->head_h, (size_t)(V * d));
+            GVC_LAUNCH_CHECK();
+        }
+    }
     else if (n == "mel_head.bias") rc = copy_w(c->head_b, src, numel, V, name, s);
     else if (n.rfind("gpt.h.", 0) == 0) {
         const size_t dot = n.find('.', 6);
@@ -350,15 +383,15 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
         GptLayer& ly = c->layers[li];
         if (rest == "ln_1.weight") rc = copy_w(ly.ln1_w, src, numel, d, name, s);
         else if (rest == "ln_1.bias") rc = copy_w(ly.ln1_b, src, numel, d, name, s);
-        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f);
+        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f, ly.qkv_h);
         else if (rest == "attn.c_attn.bias") rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s);
-        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f);
+        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f, ly.proj_h);
         else if (rest == "attn.c_proj.bias") rc = copy_w(ly.proj_b, src, numel, d, name, s);
         else if (rest == "ln_2.weight") rc = copy_w(ly.ln2_w, src, numel, d, name, s);
         else if (rest == "ln_2.bias") rc = copy_w(ly.ln2_b, src, numel, d, name, s);
-        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f);
+        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f, ly.fc_h);
         else if (rest == "mlp.c_fc.bias") rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s);
-        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f);
+        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f, ly.p2_h);
         else if (rest == "mlp.c_proj.bias") rc = copy_w(ly.p2_b, src, numel, d, name, s);
         else known = false;   // attn.bias / attn.masked_bias buffers of 4.33-era checkpoints
     } else {
@@ -434,7 +467,8 @@ static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
     const size_t lds = ((size_t)BT * A.K + (size_t)wpb * BT) * sizeof(float);
 #define GVC_GEMV_CASE(bt, ni)                                                    \
     if (BT == bt && NI == ni) {                                                  \
-        hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI>), dim3(grid), dim3(nthreads), lds, s, A); \
+        if (A.Wt16) hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI, 1>), dim3(grid), dim3(nthreads), lds, s, A); \
+        else hipLaunchKernelGGL((k_gemv<bt, ni, PRO, EPI, 0>), dim3(grid), dim3(nthreads), lds, s, A); \
         GVC_LAUNCH_CHECK();                                                      \
         return GVC_OK;                                                           \
     }
@@ -450,7 +484,9 @@ static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
 template <int PRO, int EPI>
 static int gemv_allow_big_lds() {
 #define GVC_GEMV_ATTR(bt, ni)                                                                              \
-    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemv<bt, ni, PRO, EPI>,                               \
+    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemv<bt, ni, PRO, EPI, 0>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));            \
+    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemv<bt, ni, PRO, EPI, 1>,                            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     GVC_GEMV_ATTR(1, 1) GVC_GEMV_ATTR(1, 4) GVC_GEMV_ATTR(2, 1) GVC_GEMV_ATTR(2, 4)
     GVC_GEMV_ATTR(4, 1) GVC_GEMV_ATTR(4, 4) GVC_GEMV_ATTR(8, 1) GVC_GEMV_ATTR(8, 4)
@@ -527,7 +563,7 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
     for (int l = 0; l < c->dm.n_layer; ++l) {
         const GptLayer& ly = c->layers[l];
         GemvArgs A = base_args(c, slots, row0);
-        A.Wt = ly.qkv_w; A.bias = ly.qkv_b; A.N = 3 * d; A.K = d;
+        A.Wt = ly.qkv_w; A.Wt16 = ly.qkv_h; A.bias = ly.qkv_b; A.N = 3 * d; A.K = d;
         A.ln_w = ly.ln1_w; A.ln_b = ly.ln1_b; A.embed = l == 0; A.tok_in = tok_in;
         A.out = qb;
         A.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
@@ -546,11 +582,11 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
                 GVC_LAUNCH_CHECK();
             }
             A = base_args(c, slots, row0);
-            A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
+            A.Wt = ly.fc_w; A.Wt16 = ly.fc_h; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
             A.part2 = F.part2; A.pbias = ly.proj_b; A.x2 = c->x2 + (size_t)row0 * d;
             if (!prof_skip(c, 3) && (rc = launch_gemv<PRO_LN_SUM, EPI_GELU>(c, A, B, s))) return rc;
             A = base_args(c, slots, row0);
-            A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb; A.xres = c->x2 + (size_t)row0 * d;
+            A.Wt = ly.p2_w; A.Wt16 = ly.p2_h; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb; A.xres = c->x2 + (size_t)row0 * d;
             if (!prof_skip(c, 4) && (rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
             continue;
         }
@@ -560,24 +596,24 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
         if (!prof_skip(c, 1) && (rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
 
         A = base_args(c, slots, row0);
-        A.Wt = ly.proj_w; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
+        A.Wt = ly.proj_w; A.Wt16 = ly.proj_h; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
         if (c->prefetch) A.pf = prefetch_of(c, ly.fc_w, 4 * d, d);
         if (!prof_skip(c, 2) && (rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
-        A.Wt = ly.fc_w; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
+        A.Wt = ly.fc_w; A.Wt16 = ly.fc_h; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
         if (c->prefetch) A.pf = prefetch_of(c, ly.p2_w, d, 4 * d);
         if (!prof_skip(c, 3) && (rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
-        A.Wt = ly.p2_w; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
+        A.Wt = ly.p2_w; A.Wt16 = ly.p2_h; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
         if (c->prefetch)
             A.pf = l + 1 < c->dm.n_layer ? prefetch_of(c, c->layers[l + 1].qkv_w, 3 * d, d)
                                          : prefetch_of(c, c->head_w, c->dm.vocab, d);
         if (!prof_skip(c, 4) && (rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
     }
     GemvArgs A = base_args(c, slots, row0);
-    A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+    A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
     A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
     A.out = logits_out; A.latent_out = latent_out; A.advance = 1; A.step_ctr = step_ctr;
     if (c->prefetch) A.pf = prefetch_of(c, c->layers[0].qkv_w, 3 * d, d);   // next step's first operand
@@ -716,7 +752,7 @@ extern "C" int gvc_gpt_prefill(gvc_gpt* c, const int32_t* slots, int32_t B, cons
         const int Bg = B - g < 8 ? B - g : 8;
         GemvArgs A = base_args(c, slots + g, 0);
         A.x = c->x + (size_t)g * T * d; A.x_stride = T; A.x_off = T - 1;
-        A.Wt = c->head_w; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+        A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
         A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
         A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 0;
         if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;

@@ -31,6 +31,7 @@ enum Epilogue { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 struct GemvArgs {
     // GEMV operand
     const float* Wt;     // [N][K]
+    const unsigned short* Wt16;   // bf16 copy of Wt (bf16-weights contexts), else null
     const float* bias;   // [N]
     int N, K;
     int wpb;             // waves per block
@@ -97,7 +98,9 @@ __device__ __forceinline__ void prefetch_wave(const Prefetch& P, int lane, int b
 }
 
 // PRO_LN_SUM keeps more loads in flight per lane: it is launched with at most 8 waves (256-VGPR budget)
-template <int BT, int NI, int PRO, int EPI>
+// WB = 1: the matrix is streamed from its bf16 copy (Wt16, same [N][K] layout; half the HBM bytes), products and
+// accumulation stay fp32.  Lane l then owns inputs [512j + 8l, +8) of its segment instead of [256i + 4l, +4).
+template <int BT, int NI, int PRO, int EPI, int WB = 0>
 __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const GemvArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -122,6 +125,9 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
     const bool live = row < A.N;
     const float* wp = A.Wt + (size_t)(live ? row : 0) * A.K + seg * KSEG + lane * 4;
     float4 w[NI];
+    constexpr int NB = (NI + 1) / 2;           // 16-byte bf16 loads per lane (8 inputs each)
+    uint4 wq[NB];
+    const unsigned short* wp16 = A.Wt16 + (size_t)(live ? row : 0) * A.K + seg * KSEG + lane * 8;
 
     // ---- epilogue operands are requested first: nothing is loaded after the reduction ----
     const bool fin = live && seg == 0 && lane < A.B;     // lane b finishes stream b
@@ -138,11 +144,23 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
     // weights are read exactly once per step by exactly one wave: non-temporal (evict-first) loads keep
     // them from displacing the activations / KV cache in L2 and MALL
     typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
     auto load_w = [&]() {
+        if constexpr (WB == 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(wp + i * 256));
-            w[i] = make_float4(t.x, t.y, t.z, t.w);
+            for (int i = 0; i < NI; ++i) {
+                const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(wp + i * 256));
+                w[i] = make_float4(t.x, t.y, t.z, t.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                wq[j] = make_uint4(0u, 0u, 0u, 0u);
+                if (j * 512 + lane * 8 < KSEG) {
+                    const u32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(wp16 + j * 512));
+                    wq[j] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            }
         }
     };
     // residual-stream row of stream b (layer 0 of a decode step builds it from the embeddings)
@@ -344,11 +362,27 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
         float s = 0.f;
+        if constexpr (WB == 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const float4 av = *reinterpret_cast<const float4*>(ap + b * A.K + i * 256);
-            s = fmaf(w[i].x, av.x, s); s = fmaf(w[i].y, av.y, s);
-            s = fmaf(w[i].z, av.z, s); s = fmaf(w[i].w, av.w, s);
+            for (int i = 0; i < NI; ++i) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + b * A.K + i * 256);
+                s = fmaf(w[i].x, av.x, s); s = fmaf(w[i].y, av.y, s);
+                s = fmaf(w[i].z, av.z, s); s = fmaf(w[i].w, av.w, s);
+            }
+        } else {
+            const float* ap8 = a_lds + seg * KSEG + lane * 8 + b * A.K;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j * 512 + lane * 8 < KSEG) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(ap8 + j * 512);
+                    const float4 a1 = *reinterpret_cast<const float4*>(ap8 + j * 512 + 4);
+                    // a bf16 is the upper half of an fp32: element 2i sits in the low 16 bits of word i
+                    s = fmaf(__uint_as_float(wq[j].x << 16), a0.x, s); s = fmaf(__uint_as_float(wq[j].x & 0xffff0000u), a0.y, s);
+                    s = fmaf(__uint_as_float(wq[j].y << 16), a0.z, s); s = fmaf(__uint_as_float(wq[j].y & 0xffff0000u), a0.w, s);
+                    s = fmaf(__uint_as_float(wq[j].z << 16), a1.x, s); s = fmaf(__uint_as_float(wq[j].z & 0xffff0000u), a1.y, s);
+                    s = fmaf(__uint_as_float(wq[j].w << 16), a1.z, s); s = fmaf(__uint_as_float(wq[j].w & 0xffff0000u), a1.w, s);
+                }
+            }
         }
         acc[b] = wave_sum(s);
     }
@@ -713,6 +747,8 @@ __global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const i
 __global__ void k_set_state(GptState st, const int32_t* slots, int B, int seq_len, int mel_pos);
 // gather rows [b][off .. off+n) of src [B][T][d] into dst [B][n][d]
 __global__ void k_gather_rows(const float* src, float* dst, int B, int T, int off, int n, int d);
+// round fp32 values to bf16 (nearest even) in place and write the packed bf16 copy
+__global__ void k_round_bf16(float* w, unsigned short* out, size_t n);
 // transpose Conv1D weight [K][N] -> [N][K] (LDS-tiled, 32x32)
 __global__ void k_transpose(const float* src, float* dst, int K, int N);
 

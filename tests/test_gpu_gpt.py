@@ -259,3 +259,45 @@ def test_topk50_sampling_loop_matches_oracle():
     # a draw that lands within float rounding of a CDF boundary may differ; everything before it must agree
     first_bad = [int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else m for b in range(2)]
     assert min(first_bad) >= m - 2, (toks, ref_t)
+
+
+def _round_bf16(w):
+    """the matrices a bf16-weights context rounds at bind time (include/genvc_hip.h: weight_dtype)"""
+    out = dict(w)
+    for k, v in w.items():
+        if k.endswith(("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")) or k == "mel_head.weight":
+            out[k] = v.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+@pytest.mark.parametrize("model_args,B,Tc,n", [(gcfg.TINY_MODEL_ARGS, 8, 75, 40), (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24)])
+def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n):
+    """BASELINE configs[3] direction: bf16 weight storage (fp32 math).  Because every path uses the same rounded
+    values, the oracle run on bf16-rounded weights is an exact reference: logits <= 1e-4, ids equal wherever the
+    oracle's own top-1/top-2 margin is not at rounding level."""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    _cache.clear()
+    torch.cuda.empty_cache()
+    dims = gcfg.gpt_dims(model_args)
+    w = synth.make_weights(5, synth.gpt_weight_spec(dims), device="cuda")
+    eng = GptEngine(dims, max_slots=8, max_rows=2048, weight_dtype="bf16")
+    eng.bind(w)
+    wr = _round_bf16({k: v.cpu() for k, v in w.items()})
+    cond = synth.uniform(51, "cond_latents", (B, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(51, "content_codes", (B, Tc), 256)
+    _, toks, lats = run_generate(eng, dims, cond, codes, n)
+    ref_t, ref_l, ref_logits = O.generate(wr, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    pen = [O.process_logits(ref_logits[i], torch.cat([torch.ones(B, 32 + Tc + 2, dtype=torch.long),
+                                                       torch.full((B, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
+           for i in range(n)]
+    margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)      # [B, n]
+    agree = toks.long() == ref_t
+    for b in range(B):
+        bad = (~agree[b]).nonzero()
+        if len(bad):                                  # a flip is only acceptable at a near-tie of the oracle itself
+            assert float(margins[b, int(bad[0])]) < 1e-3, (b, int(bad[0]), float(margins[b, int(bad[0])]))
+    assert agree.float().mean() > 0.9
+    first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
+    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-4)
+    eng.close()
