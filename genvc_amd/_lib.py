@@ -75,6 +75,8 @@ _SIGNATURES = {
     "gvc_hifigan_missing_weights": (C.c_int, [_P]),
     "gvc_hifigan_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "gvc_hifigan_forward_latents": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "gvc_resample_length": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "gvc_resample": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gvc_vq_argmin": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
 }
 

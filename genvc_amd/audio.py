@@ -66,15 +66,20 @@ def resample(wav, orig, new, lowpass_filter_width=6, rolloff=0.99):
     return y[..., :math.ceil(n * length / o)]
 
 
-def load_audio(audiopath, sampling_rate):
-    """reference utils.py:49-75: mono mix, resample, range sanity checks, clip to [-1, 1]; None on failure"""
+def load_audio(audiopath, sampling_rate, device=None):
+    """reference utils.py:49-75: mono mix, resample, range sanity checks, clip to [-1, 1]; None on failure.
+    With a CUDA `device` the resampling runs on the HIP kernel (gvc_resample); without one, on the torch restatement."""
     try:
         audio, lsr = read_wav(audiopath)
         if audio.size(0) != 1:
             audio = torch.mean(audio, dim=0, keepdim=True)
         assert audio.size(1) > 10
         if lsr != sampling_rate:
-            audio = resample(audio, lsr, sampling_rate)
+            if device is not None and str(device).startswith("cuda"):
+                from .engine import resample as hip_resample
+                audio = hip_resample(audio.to(device).contiguous(), lsr, sampling_rate).cpu()
+            else:
+                audio = resample(audio, lsr, sampling_rate)
     except Exception as e:                                                   # noqa: BLE001 (mirrors the reference)
         print(f"Error with {audiopath}. {e}")
         return None

@@ -325,3 +325,12 @@ class HifiganEngine:
         check(lib().gvc_hifigan_forward_latents(self._h, ptr(_f32(latents)), B, n, scale, ptr(wav), stream()),
               "hifigan_forward_latents")
         return wav
+
+
+def resample(wav, orig_sr, new_sr):
+    """wav [B,T] (CUDA) -> [B, ceil(T*new/orig)]: torchaudio.functional.resample defaults (reference utils.py:58-62)"""
+    B, T = wav.shape
+    n = lib().gvc_resample_length(T, int(orig_sr), int(new_sr))
+    out = torch.empty(B, n, device=wav.device, dtype=torch.float32)
+    check(lib().gvc_resample(ptr(_f32(wav)), B, T, int(orig_sr), int(new_sr), ptr(out), stream()), "resample")
+    return out

@@ -245,6 +245,14 @@ int gvc_hifigan_forward(gvc_hifigan* ctx, const float* x, int32_t B, int32_t T, 
 int gvc_hifigan_forward_latents(gvc_hifigan* ctx, const float* latents, int32_t B, int32_t n, int32_t scale,
                                 float* wav, gvc_stream s);
 
+/* ------------------------------------------------------------------------------------------
+ * Resampler.  Replaces torchaudio.functional.resample(audio, lsr, sampling_rate) as called by
+ * utils.load_audio (utils.py:58-62): sinc_interp_hann, lowpass_filter_width 6, rolloff 0.99.
+ * ------------------------------------------------------------------------------------------ */
+int gvc_resample_length(int32_t T, int32_t orig_sr, int32_t new_sr);
+/* x [B,T] -> out [B, gvc_resample_length(T, orig_sr, new_sr)]; synchronises the stream (file-loading path) */
+int gvc_resample(const float* x, int32_t B, int32_t T, int32_t orig_sr, int32_t new_sr, float* out, gvc_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ if __name__ == "__main__":
     else:
         model, config = model_init(args.model_path, args.device)
     model.config.top_k = args.top_k
-    src_wav = load_audio(args.src_wav, model.content_sample_rate)
-    ref_audio = load_audio(args.ref_audio, model.config.audio.sample_rate)
+    src_wav = load_audio(args.src_wav, model.content_sample_rate, device=args.device)
+    ref_audio = load_audio(args.ref_audio, model.config.audio.sample_rate, device=args.device)
     if src_wav is None or ref_audio is None:
         raise SystemExit("could not load the input audio")
 

@@ -97,3 +97,16 @@ def test_hifigan_matches_reference(gold):
             mel = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[4.0], mode="linear").contiguous()
             np.testing.assert_allclose(eng.forward(mel).cpu().numpy(), ref, atol=1e-4)
         eng.close()
+
+
+def test_resampler_matches_torchaudio_restatement():
+    """row f2: polyphase sinc resampler kernel vs the torch restatement of torchaudio.functional.resample"""
+    from genvc_amd.audio import resample as ref_resample
+    from genvc_amd.engine import resample
+    for orig, new, T in ((96000, 16000, 147486), (96000, 24000, 98835 * 4 // 4 + 3), (22050, 16000, 30000), (16000, 24000, 5000)):
+        x = synth.synth_audio(9, f"rs{orig}", T)
+        x = torch.cat([x, synth.synth_audio(10, f"rs{orig}", T, amplitude=0.3)], 0)
+        got = resample(x.to(DEV), orig, new).cpu()
+        ref = ref_resample(x, orig, new)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5)
