@@ -38,6 +38,13 @@ class HifiganDims(C.Structure):
                 ("res_dilations", (C.c_int32 * 2) * 4), ("max_batch", C.c_int32), ("max_frames", C.c_int32)]
 
 
+class HubertDims(C.Structure):
+    _fields_ = [("n_conv", C.c_int32), ("conv_dim", C.c_int32 * 8), ("conv_kernel", C.c_int32 * 8),
+                ("conv_stride", C.c_int32 * 8)] + [(n, C.c_int32) for n in (
+                    "embed_dim", "n_layers", "n_heads", "ffn_dim", "pos_conv_kernel", "pos_conv_groups", "final_dim",
+                    "max_batch", "max_samples")]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     "gvc_version": (C.c_int, []),
@@ -69,6 +76,12 @@ _SIGNATURES = {
     "gvc_dvae_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "gvc_dvae_missing_weights": (C.c_int, [_P]),
     "gvc_dvae_encode": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_hubert_create": (C.c_int, [C.POINTER(HubertDims), C.POINTER(_P)]),
+    "gvc_hubert_destroy": (C.c_int, [_P]),
+    "gvc_hubert_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
+    "gvc_hubert_missing_weights": (C.c_int, [_P]),
+    "gvc_hubert_frames": (C.c_int, [_P, C.c_int32]),
+    "gvc_hubert_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "gvc_hifigan_create": (C.c_int, [C.POINTER(HifiganDims), C.POINTER(_P)]),
     "gvc_hifigan_destroy": (C.c_int, [_P]),
     "gvc_hifigan_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),

@@ -27,6 +27,12 @@ DEFAULT_VOCODER = dict(input_feat_dim=1024, upsample_initial_channel=256, resblo
                        upsample_kernel_sizes=[16, 16, 8], resblock_type="2", hop_length=256)
 TINY_VOCODER = dict(DEFAULT_VOCODER, input_feat_dim=256, upsample_initial_channel=64)
 
+# HuBERT-base / ContentVec (fairseq HubertModel): conv extractor (dim, kernel, stride), post-LN encoder
+DEFAULT_HUBERT = dict(conv_layers=[(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2, embed_dim=768, layers=12, heads=12,
+                      ffn_dim=3072, pos_conv_kernel=128, pos_conv_groups=16, final_dim=256)
+TINY_HUBERT = dict(conv_layers=[(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2, embed_dim=128, layers=2, heads=2,
+                   ffn_dim=256, pos_conv_kernel=128, pos_conv_groups=16, final_dim=256)
+
 TINY_MODEL_ARGS = dict(DEFAULT_MODEL_ARGS, gpt_layers=2, gpt_n_model_channels=256, gpt_n_heads=4)
 TINY_CONTENT_DVAE = dict(DEFAULT_CONTENT_DVAE, codebook_dim=64, hidden_dim=32, num_resnet_blocks=1)
 
@@ -75,6 +81,7 @@ def default_config(tiny=False):
         model_args=copy.deepcopy(TINY_MODEL_ARGS if tiny else DEFAULT_MODEL_ARGS),
         content_dvae_config=copy.deepcopy(TINY_CONTENT_DVAE if tiny else DEFAULT_CONTENT_DVAE),
         vocoder_config=copy.deepcopy(TINY_VOCODER if tiny else DEFAULT_VOCODER),
+        hubert_config=copy.deepcopy(TINY_HUBERT if tiny else DEFAULT_HUBERT),
         audio=dict(sample_rate=24000),
         **DEFAULT_SAMPLING,
     )

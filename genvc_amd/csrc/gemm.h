@@ -18,11 +18,12 @@ __host__ __device__ __forceinline__ size_t fm16_index(int m, int k, int K) {
     return ((size_t)(m >> 4) * (K >> 4) + (k >> 4)) * 256 + (size_t)((((m & 15) + 16 * ((k & 15) >> 2)) << 2) + (k & 3));
 }
 
-enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_RELU = 2 };
+enum GemmAct { ACT_NONE = 0, ACT_GELU_NEW = 1, ACT_RELU = 2, ACT_GELU_ERF = 3 };
 enum GemmAAct { AACT_NONE = 0, AACT_LRELU = 1 };   // activation applied to A while it is staged (HiFi-GAN)
 
 struct GemmEpi {
     const float* bias;       // [N] or null
+    long long bias_batch_stride;   // grouped convolutions: batch = group
     int act;                 // GemmAct
     const float* resid;      // [M][ldr] or null (may alias C for in-place residual)
     int ldr;
@@ -39,7 +40,7 @@ struct GemmEpi {
 
 struct GemmArgs {
     const float* A; int lda; long long a_batch_stride;
-    const float* Wt; int ldw;
+    const float* Wt; int ldw; long long w_batch_stride;
     float* C; int ldc; long long c_batch_stride;
     int M, N, K;
     // implicit im2col for dilated convolutions over a time-major buffer: when conv_cin > 0, column k of A is
@@ -53,9 +54,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, int n, float v) {
     const GemmEpi& e = G.e;
-    if (e.bias) v += e.bias[n];
+    if (e.bias) v += e.bias[batch * e.bias_batch_stride + n];
     if (e.act == ACT_GELU_NEW) v = gelu_new(v);
     else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (e.act == ACT_GELU_ERF) v = gelu_erf(v);
     if (e.qkv) {
         const int which = n / e.d;
         const int c = n - which * e.d;

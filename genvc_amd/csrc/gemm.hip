@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
     const int kend = min(G.K, kbeg + tps * BK);
     const int nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
     const float* Ab = G.A + batch * G.a_batch_stride;
+    const float* Wb = G.Wt + batch * G.w_batch_stride;
 
     float4 ra[2], rb[2];
     auto load_tile = [&](int kt) {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
                 ra[j].x = ra[j].x > 0.f ? ra[j].x : ra[j].x * G.a_slope; ra[j].y = ra[j].y > 0.f ? ra[j].y : ra[j].y * G.a_slope;
                 ra[j].z = ra[j].z > 0.f ? ra[j].z : ra[j].z * G.a_slope; ra[j].w = ra[j].w > 0.f ? ra[j].w : ra[j].w * G.a_slope;
             }
-            rb[j] = (n < G.N && k < kend) ? *reinterpret_cast<const float4*>(G.Wt + (size_t)n * G.ldw + k)
+            rb[j] = (n < G.N && k < kend) ? *reinterpret_cast<const float4*>(Wb + (size_t)n * G.ldw + k)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };

@@ -327,6 +327,66 @@ class HifiganEngine:
         return wav
 
 
+class HubertEngine:
+    """ContentVecExtractor.extract_content_features (reference layers/content_processor.py:17-31): HuBERT-base
+    extract_features(output_layer=n_layers) + final_proj, weights under fairseq's names."""
+
+    def __init__(self, cfg, max_batch=2, max_samples=16000 * 30):
+        self.cfg = dict(cfg)
+        d = _lib.HubertDims()
+        d.n_conv = len(cfg["conv_layers"])
+        for i, (c, k, s) in enumerate(cfg["conv_layers"]):
+            d.conv_dim[i], d.conv_kernel[i], d.conv_stride[i] = c, k, s
+        d.embed_dim, d.n_layers, d.n_heads, d.ffn_dim = cfg["embed_dim"], cfg["layers"], cfg["heads"], cfg["ffn_dim"]
+        d.pos_conv_kernel, d.pos_conv_groups, d.final_dim = cfg["pos_conv_kernel"], cfg["pos_conv_groups"], cfg["final_dim"]
+        d.max_batch, d.max_samples = max_batch, max_samples
+        self.final_dim = cfg["final_dim"]
+        self._h = C.c_void_p()
+        check(lib().gvc_hubert_create(C.byref(d), C.byref(self._h)), "gvc_hubert_create")
+
+    def close(self):
+        if self._h:
+            lib().gvc_hubert_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bind(self, weights, prefix=""):
+        """weights: fairseq-named state dict; the weight-normed positional conv (weight_g, weight_v; dim=2) is
+        folded here (loader plumbing, as torch's remove_weight_norm would)."""
+        sd = {k[len(prefix):]: v for k, v in weights.items() if k.startswith(prefix) and torch.is_tensor(v)}
+        pc = "encoder.pos_conv.0."
+        if pc + "weight_v" in sd:
+            v, g = sd.pop(pc + "weight_v").float(), sd.pop(pc + "weight_g").float()
+            sd[pc + "weight"] = g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+        for name, t in sd.items():
+            if not t.is_floating_point():
+                continue
+            t = _f32(t.detach().to(torch.float32).contiguous())
+            check(lib().gvc_hubert_bind_weight(self._h, name.encode(), ptr(t), t.numel(), stream()), f"bind {name}")
+        torch.cuda.current_stream().synchronize()
+        missing = lib().gvc_hubert_missing_weights(self._h)
+        if missing:
+            raise _lib.GenvcHipError(f"{missing} HuBERT weight tensors missing after bind")
+
+    def frames(self, n_samples):
+        return lib().gvc_hubert_frames(self._h, int(n_samples))
+
+    def forward(self, wav):
+        """wav [B,T] 16 kHz -> [B,T50,final_dim]"""
+        B, T = wav.shape
+        n = self.frames(T)
+        if n < 1:
+            raise ValueError(f"{T} samples are too short for the HuBERT conv stack")
+        out = torch.empty(B, n, self.final_dim, device=wav.device, dtype=torch.float32)
+        check(lib().gvc_hubert_forward(self._h, ptr(_f32(wav)), B, T, ptr(out), stream()), "hubert_forward")
+        return out
+
+
 def resample(wav, orig_sr, new_sr):
     """wav [B,T] (CUDA) -> [B, ceil(T*new/orig)]: torchaudio.functional.resample defaults (reference utils.py:58-62)"""
     B, T = wav.shape

@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from .. import config as gcfg
-from ..layers.content_processor import SyntheticContentExtractor
+from ..layers.content_processor import ContentvecExtractor
 from ..layers.dvae import DiscreteVAE
 from ..layers.gpt import GPT
 from ..layers.hifigan import HiFiGAN
@@ -34,8 +34,9 @@ class GenVCModel(nn.Module):
                                         num_resnet_blocks=c.num_resnet_blocks, kernel_size=c.kernel_size,
                                         num_layers=c.num_layers, use_transposed_convs=False)
         self.content_sample_rate = c.get("dvae_sample_rate", 16000)
-        # ContentVec is the un-vendored fairseq boundary; a real extractor can be passed in
-        self.content_extractor = content_extractor or SyntheticContentExtractor(c.num_channels)
+        # ContentVec = HuBERT-base under fairseq's parameter names (hifigan_trainer.py:85); another extractor with
+        # the same interface can be passed in
+        self.content_extractor = content_extractor or ContentvecExtractor(config.get("hubert_config"))
         v = config.get("vocoder_config")
         if hifigan is None and v is not None:                             # hifigan_trainer.py:47-55
             hifigan = HiFiGAN(v.input_feat_dim, v.upsample_initial_channel, v.resblock_kernel_sizes,
@@ -82,6 +83,8 @@ def _finish(model, device, max_slots):
     model.to(device)
     model.gpt.init_gpt_for_inference(max_slots=max_slots)
     model.content_dvae.bind()
+    if hasattr(model.content_extractor, "bind"):
+        model.content_extractor.bind()
     if model.hifigan is not None:
         model.hifigan.bind()
     return model
@@ -112,6 +115,9 @@ def model_init_synthetic(config=None, seed=1, device="cuda", max_slots=8):
     if model.hifigan is not None:
         w.update({"hifigan." + k: v for k, v in
                   synth.make_weights(seed, synth.hifigan_weight_spec(config.vocoder_config), device=device).items()})
+    if isinstance(model.content_extractor, ContentvecExtractor):
+        w.update({"content_extractor.model." + k: v for k, v in
+                  synth.make_weights(seed, synth.hubert_weight_spec(model.content_extractor.cfg), device=device).items()})
     model.to(device)
     missing, unexpected = model.load_state_dict(w, strict=False)
     assert not unexpected, unexpected

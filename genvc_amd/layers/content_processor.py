@@ -1,15 +1,16 @@
-"""ContentVec boundary (reference layers/content_processor.py:7-34).
+"""ContentVec (reference layers/content_processor.py:7-34) on libgenvc_hip.
 
-The reference calls fairseq's HuBERT-base (`extract_features(output_layer=12)` + `final_proj`), a
-third-party model that is neither vendored in the reference nor installed here, and whose weights
-(`contentVec.pt`) are not available: SURVEY.md section 8a row 4 marks it as the boundary INPUT of this
-build (a PyTorch-ROCm restatement is the "next" row f3).  What this file provides:
+The reference calls fairseq's HuBERT-base checkpoint `contentVec.pt`: `extract_features(source, padding_mask,
+output_layer=12)[0]` followed by `final_proj`.  fairseq is neither vendored in the reference nor installed here, so
+the forward is restated (oracle/genvc_oracle.py:hubert_extract_features, pinned to HuggingFace's HubertModel) and
+built as HIP kernels behind `gvc_hubert_*` (genvc_amd/csrc/hubert.hip).  This file provides
 
-  * `contentvec_frames(T)`: the exact frame count of the HuBERT conv stack (k=[10,3,3,3,3,2,2],
-    s=[5,2,2,2,2,2,2]) so shapes downstream are right (16000 samples -> 49 frames, 96000 -> 299);
-  * `SyntheticContentExtractor`: a deterministic stand-in with the reference's interface
-    (`extract_content_features(wavs[B,T]) -> [B,T50,256]`) used for plumbing and benchmarks.
-    It is NOT ContentVec and makes no parity claim.
+  * `contentvec_frames(T)`: the frame count of the conv stack (k=[10,3,3,3,3,2,2], s=[5,2,2,2,2,2,2]);
+  * `ContentvecExtractor`: the reference's interface (`.model`, `extract_content_features(wavs[B,T]) -> [B,T50,256]`)
+    whose `.model` holds the fairseq-named parameters, so a GenVC checkpoint's `content_extractor.model.*` keys load
+    with `load_state_dict`.  The reference's `wav == 0` padding mask only marks frames whose whole receptive field is
+    exactly zero (zero-padded batches); this path handles un-padded audio;
+  * `SyntheticContentExtractor`: a cheap deterministic stand-in kept for plumbing tests (NOT ContentVec).
 """
 import torch
 from torch import nn
@@ -23,6 +24,51 @@ def contentvec_frames(n_samples):
     for k, s in zip(_K, _S):
         n = (n - k) // s + 1
     return n
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def _register(root, dotted, shape):
+    parts = dotted.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], nn.Parameter(torch.zeros(*shape), requires_grad=False))
+
+
+class ContentvecExtractor(nn.Module):
+    def __init__(self, cfg=None, max_batch=2, max_samples=16000 * 30):
+        super().__init__()
+        from .. import config as gcfg, synth
+        self.cfg = dict(cfg or gcfg.DEFAULT_HUBERT)
+        self.model = _Holder()
+        for name, (shape, _) in synth.hubert_weight_spec(self.cfg).items():
+            _register(self.model, name, shape)
+        self.max_batch, self.max_samples = max_batch, max_samples
+        self._engine = None
+
+    def bind(self):
+        from ..engine import HubertEngine
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = HubertEngine(self.cfg, max_batch=self.max_batch, max_samples=self.max_samples)
+        self._engine.bind(dict(self.model.state_dict()))
+        return self
+
+    @torch.inference_mode()
+    def extract_content_features(self, wavs):
+        """wavs [B,T] at 16 kHz -> [B,T50,256]"""
+        if self._engine is None:
+            self.bind()
+        device = next(self.model.parameters()).device
+        return self._engine.forward(wavs.to(device=device, dtype=torch.float32).contiguous())
+
+    def forward(self, wavs):
+        return self.extract_content_features(wavs)
 
 
 class SyntheticContentExtractor(nn.Module):

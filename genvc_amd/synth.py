@@ -162,6 +162,37 @@ def hifigan_weight_spec(cfg, prefix=""):
     return spec
 
 
+def hubert_weight_spec(cfg, prefix=""):
+    """fairseq HubertModel / ContentVec tensors used by extract_features + final_proj, named as in the checkpoint
+    (keys under `content_extractor.model.` in a GenVC checkpoint; reference layers/content_processor.py:10-31)."""
+    spec = {}
+    cin = 1
+    for i, (c, k, s) in enumerate(cfg["conv_layers"]):
+        spec[f"{prefix}feature_extractor.conv_layers.{i}.0.weight"] = ((c, cin, k), "conv")
+        if i == 0:
+            spec[f"{prefix}feature_extractor.conv_layers.0.2.weight"] = ((c,), "ln_w")
+            spec[f"{prefix}feature_extractor.conv_layers.0.2.bias"] = ((c,), "ln_b")
+        cin = c
+    e, f = cfg["embed_dim"], cfg["ffn_dim"]
+    spec[prefix + "layer_norm.weight"] = ((cin,), "ln_w"); spec[prefix + "layer_norm.bias"] = ((cin,), "ln_b")
+    spec[prefix + "post_extract_proj.weight"] = ((e, cin), "lin"); spec[prefix + "post_extract_proj.bias"] = ((e,), "bias")
+    kp, g = cfg["pos_conv_kernel"], cfg["pos_conv_groups"]
+    spec[prefix + "encoder.pos_conv.0.weight_g"] = ((1, 1, kp), ("wn_g", 1.0))
+    spec[prefix + "encoder.pos_conv.0.weight_v"] = ((e, e // g, kp), "conv")
+    spec[prefix + "encoder.pos_conv.0.bias"] = ((e,), "bias")
+    spec[prefix + "encoder.layer_norm.weight"] = ((e,), "ln_w"); spec[prefix + "encoder.layer_norm.bias"] = ((e,), "ln_b")
+    for l in range(cfg["layers"]):
+        p = f"{prefix}encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec[p + f"self_attn.{n}.weight"] = ((e, e), "lin"); spec[p + f"self_attn.{n}.bias"] = ((e,), "bias")
+        spec[p + "self_attn_layer_norm.weight"] = ((e,), "ln_w"); spec[p + "self_attn_layer_norm.bias"] = ((e,), "ln_b")
+        spec[p + "fc1.weight"] = ((f, e), "lin"); spec[p + "fc1.bias"] = ((f,), "bias")
+        spec[p + "fc2.weight"] = ((e, f), "lin"); spec[p + "fc2.bias"] = ((e,), "bias")
+        spec[p + "final_layer_norm.weight"] = ((e,), "ln_w"); spec[p + "final_layer_norm.bias"] = ((e,), "ln_b")
+    spec[prefix + "final_proj.weight"] = ((cfg["final_dim"], e), "lin"); spec[prefix + "final_proj.bias"] = ((cfg["final_dim"],), "bias")
+    return spec
+
+
 def make_weights(seed, spec, device="cpu", head_scale=0.05):
     """Materialise a spec.  Scales: matrices N(0,0.02)-like, LayerNorm gains near 1."""
     out = {}
@@ -176,6 +207,8 @@ def make_weights(seed, spec, device="cpu", head_scale=0.05):
             out[name] = uniform(seed, name, shape, head_scale, 0.0, device)
         elif kind == "proj":
             out[name] = uniform(seed, name, shape, 0.1, 0.0, device)
+        elif kind == "lin":
+            out[name] = uniform(seed, name, shape, 1.0 / math.sqrt(shape[1]), 0.0, device)
         elif kind == "conv":
             fan_in = shape[1] * shape[2]
             out[name] = uniform(seed, name, shape, 1.0 / math.sqrt(fan_in), 0.0, device)

@@ -253,6 +253,32 @@ int gvc_resample_length(int32_t T, int32_t orig_sr, int32_t new_sr);
 /* x [B,T] -> out [B, gvc_resample_length(T, orig_sr, new_sr)]; synchronises the stream (file-loading path) */
 int gvc_resample(const float* x, int32_t B, int32_t T, int32_t orig_sr, int32_t new_sr, float* out, gvc_stream s);
 
+/* ------------------------------------------------------------------------------------------
+ * ContentVec / HuBERT-base feature extractor.  Replaces
+ * ContentVecExtractor.extract_content_features (layers/content_processor.py:17-31):
+ *   fairseq HubertModel.extract_features(source=wav, output_layer=n_layers)[0] -> final_proj
+ * i.e. 7-layer conv extractor (GroupNorm + GELU on layer 0) -> LayerNorm -> post_extract_proj -> x + GELU(grouped
+ * positional conv) -> LayerNorm -> n_layers post-LN transformer layers -> final_proj.  No-padding path: the
+ * reference's `wav == 0` padding mask is all-false for real audio and is not modelled.
+ * Weight names are fairseq's (the keys under `content_extractor.model.` in a GenVC checkpoint), except the
+ * weight-normed positional conv, bound folded as "encoder.pos_conv.0.weight" [E, E/groups, k] (g * v / |v|, dim=2).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gvc_hubert gvc_hubert;
+typedef struct {
+    int32_t n_conv;                 /* <= 8 */
+    int32_t conv_dim[8], conv_kernel[8], conv_stride[8];
+    int32_t embed_dim, n_layers, n_heads, ffn_dim, pos_conv_kernel, pos_conv_groups, final_dim;
+    int32_t max_batch, max_samples;
+} gvc_hubert_dims;
+int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out);
+int gvc_hubert_destroy(gvc_hubert* ctx);
+int gvc_hubert_bind_weight(gvc_hubert* ctx, const char* name, const float* src, int64_t numel, gvc_stream s);
+int gvc_hubert_missing_weights(gvc_hubert* ctx);
+/* frames the conv stack yields for n_samples input samples (<= 0: too short) */
+int gvc_hubert_frames(gvc_hubert* ctx, int32_t n_samples);
+/* wav [B,T] (16 kHz) -> out [B, gvc_hubert_frames(T), final_dim] */
+int gvc_hubert_forward(gvc_hubert* ctx, const float* wav, int32_t B, int32_t T, float* out, gvc_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -359,6 +359,54 @@ def generate(w, dims, cond_latents, codes, sampling, max_new=None, seed=0, stop_
 
 
 # ---------------------------------------------------------------------------
+# row 4 / f3: ContentVec = fairseq HubertModel.extract_features(output_layer=12) + final_proj
+# (layers/content_processor.py:17-31).  fairseq is neither vendored nor installed: the arithmetic below restates the
+# HuBERT-base forward (conv extractor with GroupNorm on layer 0, post-LN encoder, weight-normed grouped positional
+# conv) and is pinned against HuggingFace's HubertModel -- the architecture fairseq checkpoints convert to -- by
+# oracle/make_golden.py.  The reference's `wav == 0` padding mask (quirk 10) is not modelled: no-padding path only.
+# ---------------------------------------------------------------------------
+
+def hubert_extract_features(w, cfg, wav, prefix=""):
+    """wav [B,T] -> [B,T50,final_dim]"""
+    g = lambda n: w[prefix + n]
+    x = wav[:, None, :]
+    for i, (c, k, s) in enumerate(cfg["conv_layers"]):
+        x = F.conv1d(x, g(f"feature_extractor.conv_layers.{i}.0.weight"), stride=s)
+        if i == 0:
+            x = F.group_norm(x, c, g("feature_extractor.conv_layers.0.2.weight"), g("feature_extractor.conv_layers.0.2.bias"), 1e-5)
+        x = F.gelu(x)
+    x = x.transpose(1, 2)
+    x = F.layer_norm(x, (x.shape[-1],), g("layer_norm.weight"), g("layer_norm.bias"), 1e-5)
+    x = F.linear(x, g("post_extract_proj.weight"), g("post_extract_proj.bias"))
+    v, gg = g("encoder.pos_conv.0.weight_v"), g("encoder.pos_conv.0.weight_g")
+    wpc = gg * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                  # weight_norm(dim=2)
+    kp = cfg["pos_conv_kernel"]
+    pc = F.conv1d(x.transpose(1, 2), wpc, g("encoder.pos_conv.0.bias"), padding=kp // 2, groups=cfg["pos_conv_groups"])
+    if kp % 2 == 0:
+        pc = pc[:, :, :-1]                                                        # SamePad
+    x = x + F.gelu(pc).transpose(1, 2)
+    e = x.shape[-1]
+    x = F.layer_norm(x, (e,), g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"), 1e-5)
+    H = cfg["heads"]
+    hd = e // H
+    B, T, _ = x.shape
+    for l in range(cfg["layers"]):
+        p = f"encoder.layers.{l}."
+        sh = lambda t: t.reshape(B, T, H, hd).transpose(1, 2)
+        q = sh(F.linear(x, g(p + "self_attn.q_proj.weight"), g(p + "self_attn.q_proj.bias")))
+        k = sh(F.linear(x, g(p + "self_attn.k_proj.weight"), g(p + "self_attn.k_proj.bias")))
+        vv = sh(F.linear(x, g(p + "self_attn.v_proj.weight"), g(p + "self_attn.v_proj.bias")))
+        a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        o = torch.matmul(a, vv).transpose(1, 2).reshape(B, T, e)
+        x = x + F.linear(o, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
+        x = F.layer_norm(x, (e,), g(p + "self_attn_layer_norm.weight"), g(p + "self_attn_layer_norm.bias"), 1e-5)
+        h = F.gelu(F.linear(x, g(p + "fc1.weight"), g(p + "fc1.bias")))
+        x = x + F.linear(h, g(p + "fc2.weight"), g(p + "fc2.bias"))
+        x = F.layer_norm(x, (e,), g(p + "final_layer_norm.weight"), g(p + "final_layer_norm.bias"), 1e-5)
+    return F.linear(x, g("final_proj.weight"), g("final_proj.bias"))
+
+
+# ---------------------------------------------------------------------------
 # row f1: HiFi-GAN generator  (layers/hifigan.py:119-157, 160-233)
 # ---------------------------------------------------------------------------
 

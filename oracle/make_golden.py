@@ -266,6 +266,51 @@ def make_hifigan(seed=13):
           "rms", float(np.sqrt((out["full_wav_1_8"] ** 2).mean())))
 
 
+@torch.inference_mode()
+def make_hubert(seed=17):
+    """fairseq is absent: pin the HuBERT restatement to HuggingFace's HubertModel (same architecture, the class
+    fairseq HuBERT/ContentVec checkpoints are converted to) loaded with the synthetic fairseq-named weights."""
+    from transformers import HubertConfig, HubertModel
+    out = dict(seed=seed)
+    for tag, c in (("tiny", gcfg.TINY_HUBERT), ("full", gcfg.DEFAULT_HUBERT)):
+        hc = HubertConfig(hidden_size=c["embed_dim"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                          intermediate_size=c["ffn_dim"], conv_dim=tuple(x[0] for x in c["conv_layers"]),
+                          conv_kernel=tuple(x[1] for x in c["conv_layers"]), conv_stride=tuple(x[2] for x in c["conv_layers"]),
+                          num_conv_pos_embeddings=c["pos_conv_kernel"], num_conv_pos_embedding_groups=c["pos_conv_groups"],
+                          feat_extract_norm="group", do_stable_layer_norm=False, hidden_act="gelu", conv_bias=False,
+                          apply_spec_augment=False, layer_norm_eps=1e-5)
+        m = HubertModel(hc).eval()
+        w = synth.make_weights(seed, synth.hubert_weight_spec(c))
+        sd = {}
+        for k, v in w.items():
+            k2 = k
+            if k.startswith("feature_extractor.conv_layers."):
+                k2 = k.replace(".0.weight", ".conv.weight").replace(".2.weight", ".layer_norm.weight").replace(".2.bias", ".layer_norm.bias")
+            elif k.startswith("layer_norm."):
+                k2 = "feature_projection." + k
+            elif k.startswith("post_extract_proj."):
+                k2 = k.replace("post_extract_proj", "feature_projection.projection")
+            elif k.startswith("encoder.pos_conv.0."):
+                k2 = {"weight_g": "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+                      "weight_v": "encoder.pos_conv_embed.conv.parametrizations.weight.original1",
+                      "bias": "encoder.pos_conv_embed.conv.bias"}[k.rsplit(".", 1)[1]]
+            elif k.startswith("encoder.layers."):
+                k2 = (k.replace("self_attn_layer_norm", "layer_norm").replace("self_attn.", "attention.")
+                       .replace("fc1.", "feed_forward.intermediate_dense.").replace("fc2.", "feed_forward.output_dense."))
+            elif k.startswith("final_proj."):
+                continue
+            sd[k2] = v
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all("masked_spec_embed" in x for x in missing), (missing, unexpected)
+        for B, T in ((1, 16000), (2, 5120), (1, 24581)):
+            wav = torch.cat([synth.synth_audio(seed + b, f"wav{T}", T) for b in range(B)], 0)
+            h = m(wav).last_hidden_state
+            feat = torch.nn.functional.linear(h, w["final_proj.weight"], w["final_proj.bias"])
+            out[f"{tag}_feat_{B}_{T}"] = feat.numpy() if tag == "tiny" or T != 24581 else feat.numpy()[:, :, :64]
+    np.savez_compressed(os.path.join(GOLD, "hubert.npz"), **out)
+    print("hubert:", {k: v.shape for k, v in out.items() if "feat" in str(k)})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -294,6 +339,8 @@ def main():
         make_sampler()
     if want("hifigan"):
         make_hifigan()
+    if want("hubert"):
+        make_hubert()
 
 
 if __name__ == "__main__":

@@ -110,3 +110,46 @@ def test_resampler_matches_torchaudio_restatement():
         ref = ref_resample(x, orig, new)
         assert got.shape == ref.shape
         np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5)
+
+
+def test_hubert_matches_hf_golden_and_oracle(gold):
+    """ContentVec forward (row f3): HIP path vs the HuggingFace HubertModel vectors and the oracle restatement"""
+    from genvc_amd.engine import HubertEngine
+    from oracle import genvc_oracle as O
+    g = gold("hubert")
+    seed = int(g["seed"])
+    for tag, c in (("tiny", gcfg.TINY_HUBERT), ("full", gcfg.DEFAULT_HUBERT)):
+        w = synth.make_weights(seed, synth.hubert_weight_spec(c), device=DEV)
+        eng = HubertEngine(c, max_batch=2, max_samples=16000 * 7)
+        eng.bind(w)
+        for B, T in ((1, 16000), (2, 5120), (1, 24581)):
+            wav = torch.cat([synth.synth_audio(seed + b, f"wav{T}", T) for b in range(B)], 0)
+            got = eng.forward(wav.to(DEV)).cpu().numpy()
+            ref = g[f"{tag}_feat_{B}_{T}"]
+            assert got.shape[:2] == ref.shape[:2] and got.shape[-1] == 256
+            np.testing.assert_allclose(got[:, :, :ref.shape[-1]], ref, atol=5e-4)      # fp32 tolerance, 12 post-LN layers
+            # second call replays the captured graph
+            np.testing.assert_array_equal(eng.forward(wav.to(DEV)).cpu().numpy(), got)
+        # a length no golden vector covers, 6 s (the bench segment): against the oracle restatement
+        wcpu = {k: v.cpu() for k, v in w.items()}
+        wav = synth.synth_audio(seed + 5, "wav6s", 96000)
+        got = eng.forward(wav.to(DEV)).cpu()
+        ref = O.hubert_extract_features(wcpu, c, wav)
+        assert got.shape == ref.shape == (1, 299, 256)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=5e-4)
+        eng.close()
+
+
+def test_hubert_rejects_short_and_oversized_input():
+    from genvc_amd.engine import HubertEngine
+    from genvc_amd._lib import GenvcHipError
+    c = gcfg.TINY_HUBERT
+    eng = HubertEngine(c, max_batch=1, max_samples=16000)
+    eng.bind(synth.make_weights(3, synth.hubert_weight_spec(c), device=DEV))
+    assert eng.frames(16000) == 49 and eng.frames(400) == 1 and eng.frames(399) == 0
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(1, 399, device=DEV))
+    with pytest.raises(GenvcHipError):
+        eng.forward(torch.zeros(1, 16001, device=DEV))
+    with pytest.raises(GenvcHipError):
+        eng.forward(torch.zeros(2, 8000, device=DEV))

@@ -147,3 +147,17 @@ def test_hifigan_vs_reference(gold):
             wav = O.vocode_latents(w, c, lat)
             assert wav.shape == (B, 1, n * 4 * 256)
             np.testing.assert_allclose(wav.numpy(), g[f"{tag}_wav_{B}_{n}"], atol=2e-5)
+
+
+def test_hubert_restatement_vs_hf(gold):
+    """ContentVec / HuBERT-base forward (fairseq absent): restatement pinned to HuggingFace's HubertModel"""
+    g = gold("hubert")
+    seed = int(g["seed"])
+    for tag, c in (("tiny", gcfg.TINY_HUBERT), ("full", gcfg.DEFAULT_HUBERT)):
+        w = synth.make_weights(seed, synth.hubert_weight_spec(c))
+        for B, T in ((1, 16000), (2, 5120), (1, 24581)):
+            wav = torch.cat([synth.synth_audio(seed + b, f"wav{T}", T) for b in range(B)], 0)
+            feat = O.hubert_extract_features(w, c, wav)
+            ref = g[f"{tag}_feat_{B}_{T}"]
+            assert feat.shape[:2] == ref.shape[:2] and feat.shape[-1] == 256
+            np.testing.assert_allclose(feat.numpy()[:, :, :ref.shape[-1]], ref, atol=2e-4)
