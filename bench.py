@@ -6,11 +6,12 @@ Workload (BASELINE.json configs[1]): GenVC_small streaming, 1 s chunks, top_k=1,
 A "step" = one synthetic utterance (10 s source @16 kHz, 3 s reference @24 kHz) pushed through the hot
 path exactly as inference_utils.synthesize_utt_streaming orders it:
     reference wav -> log-mel -> Perceiver -> 32 conditioning latents                     (once)
-    per 1 s chunk: content features -> DVAE encoder + VQ -> prefix embeddings -> prefill (48 rows)
+    per 1 s chunk: ContentVec (HuBERT-base, 16000 samples -> 49 frames) -> DVAE encoder + VQ -> prefix embeddings
+                   -> prefill (48 rows)
                    -> 24 x (sample, KV-cached decode step) in groups of 8 tokens, each group followed by the
                       vocoder call (x4 interpolation + HiFi-GAN -> 8192 samples)
-All inputs are resident in HBM before the clock starts.  Outside the timed path, and said so in `config`:
-ContentVec (third-party fairseq boundary, SURVEY 8a row 4: its 256-d features are the synthetic input).  Synthetic weights rarely emit EOS, so the token budget is
+All inputs (source and reference waveforms) are resident in HBM before the clock starts; nothing of the reference's
+per-utterance device work is outside the timed path.  Synthetic weights rarely emit EOS, so the token budget is
 fixed: round(1 s * 23.4375) = 23 tokens + the EOS step = 24 decode steps per chunk.
 N > 1: one process per GPU, utterances sharded by rank, no collective on the data path; the generated
 token ids are all-gathered (RCCL) inside the timed region.  value = utterances/s of the whole job.
@@ -68,8 +69,8 @@ class Workload:
         self.t50 = contentvec_frames(int(CHUNK_SECONDS * 16000))                       # 49
         # resident inputs: 4 distinct utterances per rank, cycled
         self.ref = [synth.synth_audio(100 + rank * 16 + u, "ref", int(REF_SECONDS * 24000)).to(device) for u in range(4)]
-        self.feat = [synth.uniform(200 + rank * 16 + u, "content_feat", (self.n_chunks, 256, self.t50), 1.0, device=device)
-                     for u in range(4)]
+        self.src = [synth.synth_audio(200 + rank * 16 + u, "src", int(SRC_SECONDS * 16000)).view(self.n_chunks, -1).to(device)
+                    for u in range(4)]
         from genvc_amd.engine import sample_params
         self.sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=1), self.dims["num_audio_tokens"], -1, 0)
         self.slots = torch.zeros(1, device=device, dtype=torch.int32)
@@ -88,9 +89,10 @@ class Workload:
         if record:
             self.ev[0].record()
         cond = m.get_gpt_cond_latents(self.ref[u % 4], 24000)                          # mel + Perceiver
-        feat = self.feat[u % 4]
+        src = self.src[u % 4]
         for c in range(self.n_chunks):
-            codes = m.content_dvae._engine.encode(feat[c:c + 1])                       # DVAE + VQ (int32 [1,13])
+            feat = m.content_extractor.extract_content_features(src[c:c + 1])          # ContentVec [1,49,256]
+            codes = m.content_dvae._engine.encode(feat, frames_major=True)             # DVAE + VQ (int32 [1,13])
             prefix = eng.prefix_embeddings(cond, codes)
             self.ids.fill_(1)
             self.ids[:, self.P] = self.dims["start_audio_token"]
@@ -112,11 +114,14 @@ class Workload:
 
 
 def cpu_baseline(wl, budget_s=10.0):
-    """The oracle (port) on the host cores, one 1 s chunk at a time (DVAE+VQ, prefix, prefill, 24 steps)."""
+    """The oracle (port) on the host cores, one 1 s chunk at a time (ContentVec, DVAE+VQ, prefix, prefill, 24 steps)."""
     from oracle import genvc_oracle as O
     m = wl.model
     w = {k[len("gpt."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("gpt.")}
     wd = {k[len("content_dvae."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("content_dvae.")}
+    pre = "content_extractor.model."
+    wh = {k[len(pre):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith(pre)}
+    hcfg = m.content_extractor.cfg
     dims = wl.dims
     norms = m.torch_mel_spectrogram_style_encoder.mel_norms
     greedy = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
@@ -138,10 +143,11 @@ def cpu_baseline(wl, budget_s=10.0):
     t0 = time.time()
     cond = O.get_gpt_cond_latents(w, wl.ref[0].cpu(), norms)
     t_ref = time.time() - t0
-    feat = wl.feat[0].cpu()
+    src = wl.src[0].cpu()
 
     def chunk(c):
-        codes = O.dvae_get_codebook_indices(wd, feat[c:c + 1])
+        feat = O.hubert_extract_features(wh, hcfg, src[c:c + 1])
+        codes = O.dvae_get_codebook_indices(wd, feat.transpose(1, 2))
         O.generate(w, dims, cond, codes, greedy, max_new=STEPS_PER_CHUNK, stop_on_eos=False)
 
     chunk(0)                                   # warm-up
@@ -156,7 +162,7 @@ def cpu_baseline(wl, budget_s=10.0):
     t_chunk = sum(times) / len(times)
     utt_s = t_ref + wl.n_chunks * t_chunk
     return {"value": 1.0 / utt_s, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} of {wl.n_chunks} one-second chunks of one utterance (DVAE+VQ, prefill 48 rows, "
+            "sample": f"{len(times)} of {wl.n_chunks} one-second chunks of one utterance (ContentVec, DVAE+VQ, prefill 48 rows, "
                       f"{STEPS_PER_CHUNK} decode steps each) + mel/Perceiver once; extrapolated to the full utterance",
             "ms_per_chunk": t_chunk * 1e3, "ms_per_decode_token_est": t_chunk * 1e3 / (STEPS_PER_CHUNK + 2),
             "rtf": utt_s / SRC_SECONDS, "host_cpus": os.cpu_count(), "cpu": platform.processor() or platform.machine()}
@@ -243,9 +249,9 @@ def main():
             "ms_per_utterance_device": utt_ms,
             "config": {"workload": "GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])",
                        "arch": "L=30 d=1024 H=4 V=1026 fp32, synthetic weights (train_genVC.py dims; no checkpoint ships)",
-                       "utterance": "10 s source @16 kHz (10 chunks x 49 content frames -> 13 codes), 3 s reference @24 kHz",
-                       "per_chunk": f"prefill {wl.P + 1} rows + {STEPS_PER_CHUNK} decode steps; HiFi-GAN vocoder every {GROUP} tokens",
-                       "excluded_from_timed_path": ["ContentVec (fairseq boundary, features are the input)"],
+                       "utterance": "10 s source @16 kHz (10 chunks x 16000 samples -> 49 ContentVec frames -> 13 codes), 3 s reference @24 kHz",
+                       "per_chunk": f"ContentVec (HuBERT-base) + DVAE/VQ + prefill {wl.P + 1} rows + {STEPS_PER_CHUNK} decode steps; HiFi-GAN vocoder every {GROUP} tokens",
+                       "excluded_from_timed_path": [],
                        "parallelism": f"replicas x{world}, utterances sharded by rank, all_gather of token ids"},
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "gvc_dvae_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),
     "gvc_dvae_missing_weights": (C.c_int, [_P]),
     "gvc_dvae_encode": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_dvae_encode_frames": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "gvc_hubert_create": (C.c_int, [C.POINTER(HubertDims), C.POINTER(_P)]),
     "gvc_hubert_destroy": (C.c_int, [_P]),
     "gvc_hubert_bind_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, _P]),

@@ -257,20 +257,47 @@ static int zero_pads(gvc_dvae* c, float* buf, int C, int T, int B, hipStream_t s
     return GVC_OK;
 }
 
-extern "C" int gvc_dvae_encode(gvc_dvae* c, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
-                               float* enc_out, gvc_stream sv) {
+static int dvae_run(gvc_dvae* c, int B, int T, int32_t* codes_out, float* enc_out, hipStream_t s);
+
+static int dvae_check(gvc_dvae* c, const float* feat, int B, int T, const int32_t* codes_out) {
     GVC_REQUIRE(c && feat && codes_out, GVC_ERR_ARG, "gvc_dvae_encode: null argument");
     GVC_REQUIRE(gvc_dvae_missing_weights(c) == 0, GVC_ERR_STATE, "%d DVAE weight tensors are not bound",
                 gvc_dvae_missing_weights(c));
     GVC_REQUIRE(B >= 1 && B <= c->dm.max_batch && T >= 1 && T <= c->dm.max_frames, GVC_ERR_ARG,
                 "dvae: B=%d T=%d outside capacity (%d, %d)", B, T, c->dm.max_batch, c->dm.max_frames);
+    return GVC_OK;
+}
+
+extern "C" int gvc_dvae_encode(gvc_dvae* c, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
+                               float* enc_out, gvc_stream sv) {
+    int rc = dvae_check(c, feat, B, T, codes_out);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)sv;
+    const int C = c->dm.channels;
+    hipLaunchKernelGGL(k_to_time_major, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(32, 8), 0, s, feat, c->buf[0], C, T, c->pad);
+    GVC_LAUNCH_CHECK();
+    return dvae_run(c, B, T, codes_out, enc_out, s);
+}
+
+extern "C" int gvc_dvae_encode_frames(gvc_dvae* c, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
+                                      float* enc_out, gvc_stream sv) {
+    int rc = dvae_check(c, feat, B, T, codes_out);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)sv;
+    const size_t C = c->dm.channels, row = C * sizeof(float);
+    // [B][T][C] -> rows [pad, pad+T) of the padded time-major buffer: one strided copy
+    GVC_CHECK_HIP(hipMemcpy2DAsync(c->buf[0] + (size_t)c->pad * C, (size_t)(T + 2 * c->pad) * row, feat, (size_t)T * row,
+                                   (size_t)T * row, B, hipMemcpyDeviceToDevice, s));
+    return dvae_run(c, B, T, codes_out, enc_out, s);
+}
+
+// input already staged in buf[0] rows [pad, pad+T)
+static int dvae_run(gvc_dvae* c, int B, int T, int32_t* codes_out, float* enc_out, hipStream_t s) {
     const int pad = c->pad;
+    (void)pad;
     int rc;
     float *cur = c->buf[0], *nxt = c->buf[1], *tmp = c->buf[2];
     int C = c->dm.channels, Tc = T;
-    hipLaunchKernelGGL(k_to_time_major, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(32, 8), 0, s, feat, cur, C, T, pad);
-    GVC_LAUNCH_CHECK();
     if ((rc = zero_pads(c, cur, C, Tc, B, s))) return rc;
     for (const ConvW& w : c->down) {                  // Conv1d(k, stride 2, pad (k-1)/2) + ReLU
         const int To = (Tc + 2 * ((w.k - 1) / 2) - w.k) / 2 + 1;

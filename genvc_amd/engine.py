@@ -238,13 +238,17 @@ class DvaeEngine:
             T = (T + 2 * ((k - 1) // 2) - k) // 2 + 1
         return T
 
-    def encode(self, feat, return_enc=False):
-        """feat [B,C,T] -> int32 codes [B,Tc] (and the encoder output [B,Tc,codebook_dim])"""
-        B, _, T = feat.shape
+    def encode(self, feat, return_enc=False, frames_major=False):
+        """feat [B,C,T] (or [B,T,C] with frames_major) -> int32 codes [B,Tc] (and the encoder output [B,Tc,codebook_dim])"""
+        if frames_major:
+            B, T, _ = feat.shape
+        else:
+            B, _, T = feat.shape
         Tc = self.out_frames(T)
         codes = torch.empty(B, Tc, device=feat.device, dtype=torch.int32)
         enc = torch.empty(B, Tc, self.cfg["codebook_dim"], device=feat.device, dtype=torch.float32) if return_enc else None
-        check(lib().gvc_dvae_encode(self._h, ptr(_f32(feat)), B, T, ptr(codes), ptr(enc), stream()), "dvae_encode")
+        fn = lib().gvc_dvae_encode_frames if frames_major else lib().gvc_dvae_encode
+        check(fn(self._h, ptr(_f32(feat)), B, T, ptr(codes), ptr(enc), stream()), "dvae_encode")
         return (codes, enc) if return_enc else codes
 
 

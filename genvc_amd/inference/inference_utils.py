@@ -67,7 +67,7 @@ def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=Fa
     final_latents, all_codes = [], []
     for src_seg in segments(src_wav, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
-        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2).contiguous())
+        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         gen = m.gpt.generate(cond_latent, codes, output_attentions=False, **_sampling_kwargs(m))[0]
         gen = gen[gen != m.gpt.stop_audio_token]                        # reference :68 (0-d collapse guarded)
         if gen.numel() == 0:
@@ -99,7 +99,7 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
     cond_latent = m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
     for src_seg in segments(src_wav, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
-        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2).contiguous())
+        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         fake = m.gpt.compute_embeddings(cond_latent, codes)
         gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,
                                   output_hidden_states=True, stream_group=max(stream_chunk_size, 1),

@@ -55,4 +55,8 @@ class DiscreteVAE(nn.Module):
         """images [B,channels,T] -> int64 [B,Tc]"""
         if self._engine is None:
             self.bind()
-        return self._engine.encode(images.to(torch.float32).contiguous()).long()
+        images = images.to(torch.float32)
+        if not images.is_contiguous() and images.transpose(1, 2).is_contiguous():
+            # the harness passes `content_feat.transpose(1, 2)`: hand the frame-major storage over as it is
+            return self._engine.encode(images.transpose(1, 2), frames_major=True).long()
+        return self._engine.encode(images.contiguous()).long()

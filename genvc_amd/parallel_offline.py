@@ -54,7 +54,7 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, **gen
     for s in range(n_seg):
         wav = torch.cat([p[s] for p in per_utt], 0)
         feat = m.content_extractor.extract_content_features(wav)
-        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2).contiguous())
+        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         gen = m.gpt.generate(cond_latent.expand(B, -1, -1).contiguous(), codes, **kw)
         out[:, s, :gen.shape[1]] = gen.to(torch.int32)
     return out

@@ -211,6 +211,10 @@ int gvc_dvae_missing_weights(gvc_dvae* ctx);
  * (ceil); enc_out (optional, may be NULL) receives the encoder output [B,Tc,codebook_dim]. */
 int gvc_dvae_encode(gvc_dvae* ctx, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
                     float* enc_out, gvc_stream s);
+/* same, from frame-major features [B,T,channels] -- the layout ContentVec emits, i.e. the harness's
+ * `get_codebook_indices(content_feat.transpose(1, 2))` (inference/inference_utils.py:53,167) without the transpose */
+int gvc_dvae_encode_frames(gvc_dvae* ctx, const float* feat, int32_t B, int32_t T, int32_t* codes_out,
+                           float* enc_out, gvc_stream s);
 /* standalone VQ: x [N,dim], embed [dim,n_embed] (reference layout) -> idx int32 [N] */
 int gvc_vq_argmin(const float* x, const float* embed, int32_t N, int32_t dim, int32_t n_embed,
                   int32_t* idx, float* work /* N*n_embed floats */, gvc_stream s);

@@ -74,6 +74,16 @@ def test_shell_state_dict_names_match_reference():
     dspec = synth.dvae_weight_spec(c)
     assert set(dv.state_dict()) == set(dspec)
     assert all(tuple(dv.state_dict()[k].shape) == tuple(dspec[k][0]) for k in dspec)
+    # ContentVec: fairseq HubertModel parameter names under `.model` (content_processor.py:14, model_init.py:29-30)
+    from genvc_amd.layers.content_processor import ContentvecExtractor
+    cv = ContentvecExtractor(gcfg.TINY_HUBERT)
+    hspec = synth.hubert_weight_spec(gcfg.TINY_HUBERT)
+    hsd = cv.model.state_dict()
+    assert set(hsd) == set(hspec) and all(tuple(hsd[k].shape) == tuple(hspec[k][0]) for k in hspec)
+    assert "model.encoder.layers.1.self_attn.q_proj.weight" in cv.state_dict()
+    full = synth.hubert_weight_spec(gcfg.DEFAULT_HUBERT)
+    n = sum(int(np.prod(v[0])) for v in full.values())
+    assert 94_000_000 < n < 96_000_000                               # HuBERT-base
 
 
 def test_harness_segmentation_and_chunks_match_oracle():
