@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgenvc_hip.so")
+LIB_PATH = os.environ.get("GENVC_HIP_LIB") or os.path.join(_HERE, "lib", "libgenvc_hip.so")     # override: A/B runs of two builds
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
