@@ -36,6 +36,7 @@ struct GemmEpi {
     int d, n_head, head_dim, max_seq, T;
     float* kcache; float* vcache;
     const int32_t* slots;
+    const int32_t* base_len;  // nullable: per-slot cached length; row t of batch b lands at position base_len[slot] + t
 };
 
 struct GemmArgs {
@@ -66,9 +67,10 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, 
         } else {
             const int b = m / e.T, t = m - b * e.T;
             const int slot = e.slots[b];
+            const int pos = t + (e.base_len ? e.base_len[slot] : 0);
             const int h = c / e.head_dim, j = c - h * e.head_dim;
             float* cache = which == 1 ? e.kcache : e.vcache;
-            cache[(((size_t)slot * e.n_head + h) * e.max_seq + t) * e.head_dim + j] = v;
+            cache[(((size_t)slot * e.n_head + h) * e.max_seq + pos) * e.head_dim + j] = v;
         }
         return;
     }

@@ -99,6 +99,20 @@ __global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const i
     }
 }
 
+// one workgroup per stream: x[b] = mel_embedding[tok[b]] + mel_pos_embedding[mel_pos[slot[b]]]  (gpt_inference.py:92-96)
+__global__ void k_embed_decode_rows(float* x, const int32_t* tok, const int32_t* slots, GptState st, const float* mel_emb,
+                                    const float* mel_pos, int d) {
+    const int b = blockIdx.x;
+    const float* e = mel_emb + (size_t)tok[b] * d;
+    const float* p = mel_pos + (size_t)st.mel_pos[slots[b]] * d;
+    float* dst = x + (size_t)b * d;
+    for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(e + k);
+        const float4 c = *reinterpret_cast<const float4*>(p + k);
+        *reinterpret_cast<float4*>(dst + k) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    }
+}
+
 __global__ void k_set_state(GptState st, const int32_t* slots, int B, int seq_len, int mel_pos) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
@@ -184,6 +198,7 @@ struct gvc_gpt {
     float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
     int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
+    int rows_decode_min = 7;                      // batches of at least this many streams decode on the MFMA rows path (0: never)
     float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
     int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step
     GptState st;
@@ -253,6 +268,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     }
     c->n_expected = 10 + 12 * (int)L;
     if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
+    if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
     c->bf16 = D.weight_dtype == 1;
     GVC_REQUIRE(D.weight_dtype == 0 || D.weight_dtype == 1, GVC_ERR_ARG, "weight_dtype must be 0 (fp32) or 1 (bf16)");
     if (c->bf16) {
@@ -523,8 +539,8 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     return A;
 }
 
-static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s) {
-    return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s);
+static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s, bool wide = false) {
+    return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s, wide && c->hd == 256);
 }
 
 static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
@@ -621,6 +637,35 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
     return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
 }
 
+static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len = nullptr);
+
+// Batched decode step on the MFMA path: the B new rows go through the skinny fragment-major GEMMs (weights streamed
+// once for up to 128 streams) instead of the 8-stream GEMV groups.  Same arithmetic as a prefill of one row per stream
+// appended at each slot's cached length.
+static bool rows_decode_ok(const gvc_gpt* c, int B) {
+    return c->rows_decode_min > 0 && B >= c->rows_decode_min && B <= 128 && c->skinny_prefill && c->wfm &&
+           c->dm.d_model % 256 == 0 && (long long)4 * B * c->dm.d_model <= c->work_cap / 2 && B <= c->dm.max_rows;
+}
+
+static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* tok_in, float* logits_out, float* latent_out,
+                       int32_t* step_ctr, hipStream_t s) {
+    const int d = c->dm.d_model;
+    int rc;
+    hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d);
+    GVC_LAUNCH_CHECK();
+    if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len))) return rc;
+    for (int g = 0; g < B; g += 8) {
+        const int Bg = B - g < 8 ? B - g : 8;
+        GemvArgs A = base_args(c, slots + g, g);
+        A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+        A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
+        A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 1;
+        A.step_ctr = g + 8 >= B ? step_ctr : nullptr;
+        if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;
+    }
+    return GVC_OK;
+}
+
 static int check_ready(gvc_gpt* c) {
     GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
@@ -634,6 +679,7 @@ extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, 
     if (rc) return rc;
     GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "decode_step: B=%d outside [1,%d]", B, c->dm.max_slots);
     hipStream_t s = (hipStream_t)sv;
+    if (rows_decode_ok(c, B)) return decode_rows(c, slots, B, tok_in, logits_out, latent_out, nullptr, s);
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         if ((rc = decode_group(c, slots + g, Bg, g, tok_in + g, logits_out + (size_t)g * c->dm.vocab,
@@ -663,11 +709,12 @@ extern "C" int gvc_gpt_prefix_embeddings(gvc_gpt* c, const float* cond, int32_t 
     return GVC_OK;
 }
 
-// block stack over B*T rows already in c->x; K/V of every row go to the slots' cache (positions 0..T-1).
+// block stack over B*T rows already in c->x; K/V of every row go to the slots' cache (positions 0..T-1, or
+// base_len[slot] + 0..T-1 when the rows continue cached sequences: the batched decode step is T = 1).
 // rows <= 128 (a streaming prefill): skinny MFMA GEMMs; the N = d projections are K-split over 4 workgroup
 // rows and their raw partial sums are folded into the NEXT LayerNorm launch (k_ln_sum_rows), so a layer is
 // 7 launches.  Larger row counts (batched offline prefill, latent re-pass) use the tiled GEMM.
-static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s) {
+static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len) {
     const int d = c->dm.d_model, rows = B * T;
     int rc;
     const bool skinny = c->skinny_prefill && c->wfm && rows <= 128 && d % 256 == 0 && (long long)4 * rows * d <= c->work_cap / 2;
@@ -690,14 +737,16 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         memset(&G, 0, sizeof(G));
         G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
-        G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots;
+        G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
         G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
         G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
         if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         AttnArgs At = gpt_attn_args(c, l, slots);
-        At.q = c->q; At.T = T; At.base_len = nullptr; At.out = c->a; At.out_stride = d; At.out_fm16 = skinny ? 1 : 0;
-        if ((rc = launch_attention(c, At, 1, rows, true, s))) return rc;
+        At.q = c->q; At.T = T; At.base_len = base_len;
+        At.out = c->a; At.out_stride = d; At.out_fm16 = skinny ? 1 : 0;
+        // one new row per cached stream (batched decode): 16 waves share the keys of a (row, head)
+        if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
         memset(&G, 0, sizeof(G));
         G.A = c->a; G.lda = d; G.Wt = skinny ? ly.proj_f : ly.proj_w; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
@@ -827,6 +876,9 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) 
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     if (pf) c->prog_active = c->prog;        // every launch of the step bumps the progress counter
     rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
+    if (rc == GVC_OK && rows_decode_ok(c, B))
+        rc = decode_rows(c, c->gen_call->slots, B, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
+    else
     for (int g = 0; g < B && rc == GVC_OK; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         const bool last = g + 8 >= B;
@@ -867,7 +919,7 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     GVC_LAUNCH_CHECK();
     // ids_stride bounds the cached positions of this run (prefix + 1 + every step the caller will ask for)
     const bool fused = fused_ok(c, B, ids_stride);
-    const int key = B * 2 + (fused ? 1 : 0);
+    const int key = B * 2 + (fused ? 1 : 0);          // (rows mode is a pure function of B: same key)
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;

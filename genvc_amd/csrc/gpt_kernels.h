@@ -471,9 +471,11 @@ struct AttnArgs {
     int out_fm16;              // DIRECT: write `out` in the FM16 layout of gemm.h (row length out_stride)
 };
 
-template <int HD, bool DIRECT>
-__global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
-    if (threadIdx.x >= 256) {      // optional prefetcher wave, see prefetch_wave()
+// NW = waves that share the keys of one (chunk, head, row): 4, or 16 for the batched decode rows (one new row over a
+// long cached context: 16 waves x U keys are requested per round trip instead of 4 x U)
+template <int HD, bool DIRECT, int NW = 4>
+__global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const AttnArgs A) {
+    if (NW == 4 && threadIdx.x >= 256) {      // optional prefetcher wave, see prefetch_wave()
         if (A.pf.base)
             prefetch_wave(A.pf, threadIdx.x & 63, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
                           gridDim.x * gridDim.y * gridDim.z);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
         __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int LPK = HD / 4;          // lanes per key
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
-    constexpr int NG = 4 * KPW;          // softmax states per block
+    constexpr int NG = NW * KPW;         // softmax states per block
     __shared__ float m_s[NG], l_s[NG];
     __shared__ __attribute__((aligned(16))) float o_s[NG][HD];
 
@@ -506,14 +508,14 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
 
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int U = 4;
-    for (int kb = k0 + wave * KPW + kl; kb < k1 + (U * 4 * KPW); kb += U * 4 * KPW) {
+    constexpr int U = NW == 4 ? 4 : 8;
+    for (int kb = k0 + wave * KPW + kl; kb < k1 + (U * NW * KPW); kb += U * NW * KPW) {
         if (kb - kl - wave * KPW >= k1) break;           // uniform per block iteration
         float4 kv[U], vv[U];
         float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = kb + u * 4 * KPW;
+            const int key = kb + u * NW * KPW;
             const bool ok = key < k1;
             const size_t off = (size_t)(ok ? key : k0) * A.k_row_stride;
             kv[u] = *reinterpret_cast<const float4*>(kp + off);
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(320) void k_attention(const AttnArgs A) {
             float d = dot4(q4, kv[u]);
             if constexpr (LPK == 64) d = wave_sum(d);
             else d = row16_sum(d);                         // LPK == 16
-            s[u] = (kb + u * 4 * KPW < k1) ? d * A.scale : -INFINITY;
+            s[u] = (kb + u * NW * KPW < k1) ? d * A.scale : -INFINITY;
         }
         float mn = m;
 #pragma unroll
@@ -713,11 +715,12 @@ static __global__ __launch_bounds__(64) void k_step_prefetcher(const PrefetchEnt
 
 // host launcher shared by the GPT and Perceiver contexts
 static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& T, int chunks, int rows, bool direct,
-                                      hipStream_t s) {
+                                      hipStream_t s, bool wide = false) {
     dim3 grid(chunks, n_head, rows);
     dim3 block(T.pf.base ? 320 : 256);
     if (head_dim == 256) {
-        if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
+        if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16>), grid, dim3(1024), 0, s, T);
+        else if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
         else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);
     } else if (head_dim == 64) {
         if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, block, 0, s, T);

@@ -301,3 +301,47 @@ def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n
     first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
     np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("B", [8, 16, 19])
+def test_rows_mode_batched_decode_vs_oracle(B):
+    """B >= 7 streams decode on the MFMA rows path (one pass over the weights for up to 128 streams): ragged cache
+    lengths, teacher-forced logits/latents against the oracle, and the K/V rows it appends feed later steps."""
+    from oracle import genvc_oracle as O
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3, max_slots=24)
+    wc = cpu_weights(w)
+    dev = "cuda"
+    slots = torch.randperm(24, generator=torch.Generator().manual_seed(B))[:B].to(dev).int().contiguous()
+    caches, n = [], 6
+    for i in range(B):
+        Tc = 5 + (3 * i) % 17                                          # ragged prefixes
+        cond = synth.uniform(50 + i, "cond_latents", (1, 32, dims["d_model"]), 1.0)
+        codes = synth.integers(50 + i, "content_codes", (1, Tc), 256)
+        prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+        eng.prefill(slots[i:i + 1].contiguous(), prefix, want_outputs=False)
+        pe, _ = O.compute_embeddings(wc, dims, cond, codes)
+        caches.append(O.gpt_prefill(wc, dims, pe)[2])
+    toks = synth.integers(61, "toks", (B, n), 1024)
+    for j in range(1, n + 1):
+        lg, lat = eng.decode_step(slots, toks[:, j - 1].to(dev).int().contiguous())
+        for i in range(B):
+            z, logits, caches[i] = O.gpt_decode_step(wc, dims, caches[i], toks[i:i + 1, j - 1], j)
+            np.testing.assert_allclose(lg[i:i + 1].cpu().numpy(), logits.numpy(), atol=1e-4)
+            np.testing.assert_allclose(lat[i:i + 1].cpu().numpy(), z.numpy(), atol=1e-4)
+
+
+def test_rows_mode_generate_matches_single_stream_tokens(gold):
+    """greedy ids of 16 streams generated together (rows path, graph-replayed) = the reference's ids of each stream
+    (golden tiny fixture replicated across the batch with different neighbours)"""
+    g = gold("gpt_tiny")
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, int(g["seed"]), max_slots=24)
+    cond, codes = inputs(g, dims)
+    Bg = cond.shape[0]
+    reps = 16 // Bg
+    cond16 = cond.repeat(reps, 1, 1)
+    codes16 = codes.repeat(reps, 1)
+    n = g["tokens"].shape[1]
+    _, toks, lats = run_generate(eng, dims, cond16, codes16, n)
+    exp = np.tile(g["tokens"], (reps, 1))
+    assert np.array_equal(toks.numpy(), exp), "rows-mode greedy ids differ from the reference"
+    np.testing.assert_allclose(lats[:Bg, :, :32].numpy(), g["latents_slice"], atol=1e-4)
