@@ -15,6 +15,10 @@ per-utterance device work is outside the timed path.  Synthetic weights rarely e
 fixed: round(1 s * 23.4375) = 23 tokens + the EOS step = 24 decode steps per chunk.
 N > 1: one process per GPU, utterances sharded by rank, no collective on the data path; the generated
 token ids are all-gathered (RCCL) inside the timed region.  value = utterances/s of the whole job.
+
+`--streams B` (default 1 = the headline configuration) steps B concurrent streams per GPU together (BASELINE
+configs[3] shape: shared launches, one decode step for all streams; the MFMA rows path from 7 streams up); a step is
+then B utterances and the JSON line says so in `config.workload`.
 """
 import argparse
 import json
@@ -57,10 +61,11 @@ def kernel_bytes(dims, which, S):
 
 
 class Workload:
-    def __init__(self, device, rank):
+    def __init__(self, device, rank, streams=1):
         from genvc_amd.inference.model_init import model_init_synthetic
         self.dev = device
-        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=8)
+        self.S = S = streams
+        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=max(8, S))
         m = self.model
         self.dims = m.gpt.dims()
         self.eng = m.gpt.engine
@@ -69,19 +74,20 @@ class Workload:
         self.t50 = contentvec_frames(int(CHUNK_SECONDS * 16000))                       # 49
         # resident inputs: 4 distinct utterances per rank, cycled
         self.ref = [synth.synth_audio(100 + rank * 16 + u, "ref", int(REF_SECONDS * 24000)).to(device) for u in range(4)]
-        self.src = [synth.synth_audio(200 + rank * 16 + u, "src", int(SRC_SECONDS * 16000)).view(self.n_chunks, -1).to(device)
-                    for u in range(4)]
+        # src[u]: [n_chunks, S, 16000] -- S concurrent streams, chunk-major
+        self.src = [torch.stack([synth.synth_audio(200 + rank * 16 + u + 977 * j, "src", int(SRC_SECONDS * 16000))
+                                 .view(self.n_chunks, -1) for j in range(S)], 1).contiguous().to(device) for u in range(4)]
         from genvc_amd.engine import sample_params
         self.sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=1), self.dims["num_audio_tokens"], -1, 0)
-        self.slots = torch.zeros(1, device=device, dtype=torch.int32)
+        self.slots = torch.arange(S, device=device, dtype=torch.int32)
         n_tok = self.n_chunks * STEPS_PER_CHUNK
-        self.toks = torch.zeros(1, n_tok, device=device, dtype=torch.int32)
-        self.lats = torch.zeros(1, n_tok, self.dims["d_model"], device=device)
+        self.toks = torch.zeros(S, n_tok, device=device, dtype=torch.int32)
+        self.lats = torch.zeros(S, n_tok, self.dims["d_model"], device=device)
         self.Tc = m.content_dvae._engine.out_frames(self.t50)                          # 13
         self.P = 32 + self.Tc + 2
-        self.ids = torch.ones(1, self.P + 1 + STEPS_PER_CHUNK + 8, device=device, dtype=torch.int32)
-        self.ids_len = torch.zeros(1, device=device, dtype=torch.int32)
-        self.fin = torch.zeros(1, device=device, dtype=torch.int32)
+        self.ids = torch.ones(S, self.P + 1 + STEPS_PER_CHUNK + 8, device=device, dtype=torch.int32)
+        self.ids_len = torch.zeros(S, device=device, dtype=torch.int32)
+        self.fin = torch.zeros(S, device=device, dtype=torch.int32)
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
     def utterance(self, u, record=False):
@@ -89,9 +95,11 @@ class Workload:
         if record:
             self.ev[0].record()
         cond = m.get_gpt_cond_latents(self.ref[u % 4], 24000)                          # mel + Perceiver
+        if self.S > 1:
+            cond = cond.expand(self.S, -1, -1).contiguous()                            # one reference speaker for the batch
         src = self.src[u % 4]
         for c in range(self.n_chunks):
-            feat = m.content_extractor.extract_content_features(src[c:c + 1])          # ContentVec [1,49,256]
+            feat = m.content_extractor.extract_content_features(src[c])                # ContentVec [S,49,256]
             codes = m.content_dvae._engine.encode(feat, frames_major=True)             # DVAE + VQ (int32 [1,13])
             prefix = eng.prefix_embeddings(cond, codes)
             self.ids.fill_(1)
@@ -143,7 +151,7 @@ def cpu_baseline(wl, budget_s=10.0):
     t0 = time.time()
     cond = O.get_gpt_cond_latents(w, wl.ref[0].cpu(), norms)
     t_ref = time.time() - t0
-    src = wl.src[0].cpu()
+    src = wl.src[0][:, 0].cpu()
 
     def chunk(c):
         feat = O.hubert_extract_features(wh, hcfg, src[c:c + 1])
@@ -174,6 +182,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,7 +196,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(device))
 
-    wl = Workload(device, rank)
+    wl = Workload(device, rank, args.streams)
     for u in range(args.warmup):
         wl.utterance(u)
 
@@ -224,7 +233,7 @@ def main():
         tok = torch.zeros(1, device=device, dtype=torch.int32)
         kern = []
         for which in range(6):
-            avg, n = wl.eng.time_kernel(which, wl.slots, tok, 128 if which == 5 else 32)
+            avg, n = wl.eng.time_kernel(which, wl.slots[:1].contiguous(), tok, 128 if which == 5 else 32)
             per_step = 1 if which == 5 else wl.dims["n_layer"]
             kern.append({"kernel": KERNEL_NAMES[which], "avg_us": avg, "launches_timed": n, "launches_per_step": per_step,
                          "bytes": kernel_bytes(wl.dims, which, S)})
@@ -238,16 +247,18 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get(kern[dom]["kernel"])
-        n_utts = args.steps * world
+        n_utts = args.steps * world * args.streams
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "utterances/s (streaming, 1 s chunks; with RTF and first-chunk latency)",
             "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms,
+            "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms, "streams_per_gpu": args.streams,
             "ms_per_utterance_device": utt_ms,
-            "config": {"workload": "GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])",
+            "config": {"workload": ("GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])" if args.streams == 1
+                                    else f"GenVC_small streaming, 1 s chunks, top_k=1, {args.streams} concurrent streams per GPU stepped together "
+                                         "(BASELINE configs[3] shape, fp32); one step = that many utterances"),
                        "arch": "L=30 d=1024 H=4 V=1026 fp32, synthetic weights (train_genVC.py dims; no checkpoint ships)",
                        "utterance": "10 s source @16 kHz (10 chunks x 16000 samples -> 49 ContentVec frames -> 13 codes), 3 s reference @24 kHz",
                        "per_chunk": f"ContentVec (HuBERT-base) + DVAE/VQ + prefill {wl.P + 1} rows + {STEPS_PER_CHUNK} decode steps; HiFi-GAN vocoder every {GROUP} tokens",

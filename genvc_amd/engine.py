@@ -110,11 +110,18 @@ class GptEngine:
         return tok
 
     def generate(self, slots, ids, ids_len, finished, params, i0, n_steps, tokens_out, latents_out):
+        """tokens_out [B, >= i0+n_steps] int32 and latents_out [B, >= i0+n_steps, d] may be column slices of larger
+        buffers (row strides are passed on); step i of this call lands in column i0 + i."""
         B = slots.shape[0]
+        assert tokens_out.is_cuda and tokens_out.dtype == torch.int32 and tokens_out.stride(1) == 1
+        lat_stride = 0
+        if latents_out is not None:
+            assert latents_out.is_cuda and latents_out.dtype == torch.float32 and latents_out.stride(2) == 1
+            assert latents_out.stride(1) == self.d and latents_out.stride(0) % self.d == 0
+            lat_stride = latents_out.stride(0) // self.d
         check(lib().gvc_gpt_generate(self._h, ptr(_i32(slots)), B, ptr(_i32(ids)), ids.shape[1], ptr(_i32(ids_len)),
-                                     ptr(_i32(finished)), C.byref(params), i0, n_steps, ptr(_i32(tokens_out)),
-                                     tokens_out.shape[1], ptr(latents_out),
-                                     latents_out.shape[1] if latents_out is not None else 0, stream()), "generate")
+                                     ptr(_i32(finished)), C.byref(params), i0, n_steps, ptr(tokens_out),
+                                     tokens_out.stride(0), ptr(latents_out), lat_stride, stream()), "generate")
 
     def time_kernel(self, which, slots, tok, n_steps):
         """(mean us per launch, launches) of one kernel class of the decode step, launched back to back"""

@@ -134,3 +134,76 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
     if return_details or not pred:
         return dict(wav=torch.cat(pred, -1) if pred else None, latents=chunks_lat, tokens=tokens, latency=latency, rtf=rtf)
     return torch.cat(pred, dim=-1)
+
+
+@torch.inference_mode()
+def synthesize_streams_streaming(genVC_mdl, src_wavs, tgt_audios, seg_len=1.0, stream_chunk_size=8, return_details=True):
+    """BASELINE configs[3]: B concurrent streams stepped together.  Each stream is converted exactly as
+    `synthesize_utt_streaming` converts it on its own (same segments, same per-stream EOS rule, same vocoder grouping and
+    cross-fade); the streams only SHARE the launches: ContentVec / DVAE / prefill / vocoder run on the batch and one
+    decode step serves every stream (the MFMA rows path from 7 streams up).
+
+    src_wavs [B,T] (equal lengths), tgt_audios [B,Tr] or [1,Tr] (one reference for all).
+    Returns per-stream lists: wav [B] tensors, tokens, plus first-chunk latency and the batch RTF."""
+    m = genVC_mdl
+    B, total = src_wavs.shape
+    min_len = int(0.32 * m.content_sample_rate)
+    begin = time.time()
+    latency = None
+    src_wavs = src_wavs.to(m.device)
+    seg = int(seg_len * m.content_sample_rate)
+    sr = m.config.audio.sample_rate
+    tgt = tgt_audios.to(m.device)
+    conds = [m.get_gpt_cond_latents(tgt[i:i + 1], sr) for i in range(tgt.shape[0])]
+    cond_latent = torch.cat(conds if len(conds) == B else conds * B, 0)
+    stop = m.gpt.stop_audio_token
+    prev, overlap = [None] * B, [None] * B
+    pred, tokens = [[] for _ in range(B)], [[] for _ in range(B)]
+    for src_seg in segments(src_wavs, seg, min_len):
+        feat = m.content_extractor.extract_content_features(src_seg)
+        codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+        fake = m.gpt.compute_embeddings(cond_latent, codes)
+        gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,
+                                  output_hidden_states=True, stream_group=max(stream_chunk_size, 1),
+                                  **_sampling_kwargs(m))
+        alive = [True] * B                        # a stream stops with its own EOS step (latent included, :189-196)
+        g_tok, g_lat = [], []
+        is_end = False
+        while not is_end:
+            try:
+                x, latent = next(gen)
+                g_tok.append(x)
+                g_lat.append(latent)
+            except StopIteration:
+                is_end = True
+            if (is_end and g_tok) or (stream_chunk_size > 0 and len(g_tok) >= stream_chunk_size):
+                toks = torch.stack(g_tok, 1)                                  # [B,n]
+                lats = torch.stack(g_lat, 1)                                  # [B,n,d]
+                toks_h = toks.cpu()
+                keep = []
+                for b in range(B):
+                    nb = 0
+                    if alive[b]:
+                        row = toks_h[b]
+                        hit = (row == stop).nonzero()
+                        nb = int(hit[0]) + 1 if hit.numel() else row.shape[0]
+                        if hit.numel():
+                            alive[b] = False
+                        tokens[b].append(toks[b:b + 1, :nb])
+                    keep.append(nb)
+                # streams with the same group length share one vocoder call
+                for nb in sorted(set(k for k in keep if k > 0)):
+                    idx = [b for b in range(B) if keep[b] == nb]
+                    audio = _vocode(m, lats[idx, :nb].contiguous())
+                    if audio is None:
+                        continue
+                    for j, b in enumerate(idx):
+                        chunk, prev[b], overlap[b] = handle_chunks(audio[j].squeeze(), prev[b], overlap[b], 1024)
+                        pred[b].append(chunk)
+                g_tok, g_lat = [], []
+                if latency is None:
+                    torch.cuda.synchronize()
+                    latency = time.time() - begin
+    torch.cuda.synchronize()
+    rtf = (time.time() - begin) / (total / m.content_sample_rate)
+    return dict(wav=[torch.cat(p, -1) if p else None for p in pred], tokens=tokens, latency=latency, rtf=rtf)

@@ -82,11 +82,14 @@ def _finish(model, device, max_slots):
     model.eval()
     model.to(device)
     model.gpt.init_gpt_for_inference(max_slots=max_slots)
-    model.content_dvae.bind()
+    mb = max(2, max_slots)
+    model.content_dvae.bind(max_batch=max(8, max_slots))
     if hasattr(model.content_extractor, "bind"):
+        if hasattr(model.content_extractor, "max_batch"):
+            model.content_extractor.max_batch = mb
         model.content_extractor.bind()
     if model.hifigan is not None:
-        model.hifigan.bind()
+        model.hifigan.bind(max_batch=mb)
     return model
 
 

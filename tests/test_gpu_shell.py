@@ -101,3 +101,24 @@ def test_harness_streaming_and_offline_agree():
             row = allt[i, sidx]
             assert torch.equal(row[row != m.gpt.stop_audio_token].long(), c)
     _m.clear()
+
+
+@pytest.mark.parametrize("B", [3, 8])
+def test_concurrent_streams_equal_single_stream_conversions(B):
+    """BASELINE configs[3]: B streams stepped together (shared launches; rows-path decode from 7 streams up) give each
+    stream the tokens and waveform it gets when converted alone."""
+    from genvc_amd.inference.inference_utils import synthesize_streams_streaming, synthesize_utt_streaming
+    m = tiny_model(3)
+    m.gpt.max_gen_mel_tokens = 30
+    srcs = torch.cat([synth.synth_audio(70 + i, "src", 32000) for i in range(B)], 0)      # 2 s each: two 1 s segments
+    ref = synth.synth_audio(6, "ref", 72000)
+    out = synthesize_streams_streaming(m, srcs, ref, seg_len=1.0, stream_chunk_size=8)
+    assert out["latency"] is not None and out["rtf"] > 0
+    for i in range(B):
+        one = synthesize_utt_streaming(m, srcs[i:i + 1], ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+        t_one = torch.cat(one["tokens"], 1)[0]
+        t_b = torch.cat(out["tokens"][i], 1)[0]
+        assert torch.equal(t_one.cpu(), t_b.cpu()), f"stream {i}: tokens differ"
+        assert out["wav"][i].shape == one["wav"].shape
+        np.testing.assert_allclose(out["wav"][i].cpu().numpy(), one["wav"].cpu().numpy(), atol=2e-4)
+    _m.clear()
