@@ -30,7 +30,7 @@ def main():
         cond = timed("mel+perceiver (once)", lambda: m.get_gpt_cond_latents(wl.ref[r % 4], 24000))
         src = wl.src[r % 4]
         for c in range(wl.n_chunks):
-            feat = timed("contentvec", lambda: m.content_extractor.extract_content_features(src[c:c + 1]))
+            feat = timed("contentvec", lambda: m.content_extractor.extract_content_features(src[c]))
             codes = timed("dvae+vq", lambda: m.content_dvae._engine.encode(feat, frames_major=True))
             prefix = timed("prefix_emb", lambda: eng.prefix_embeddings(cond, codes))
 
