@@ -110,8 +110,10 @@ int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
     const int tm = cdiv(G.M, BM), tn = cdiv(G.N, BN);
     const long long tiles = (long long)tm * tn * batch;
     int SK = 1;
-    if (tiles < 128 && G.work) {
-        SK = (int)((192 + tiles - 1) / tiles);
+    static const int sk_tiles = getenv("GVC_GEMM_SK_TILES") ? atoi(getenv("GVC_GEMM_SK_TILES")) : 128;
+    static const int sk_target = getenv("GVC_GEMM_SK_TARGET") ? atoi(getenv("GVC_GEMM_SK_TARGET")) : 192;
+    if (tiles < sk_tiles && G.work) {
+        SK = (int)((sk_target + tiles - 1) / tiles);
         const int max_by_k = G.K / (4 * BK) > 0 ? G.K / (4 * BK) : 1;
         if (SK > max_by_k) SK = max_by_k;
         if (SK > 16) SK = 16;
