@@ -197,6 +197,11 @@ struct gvc_gpt {
     long long work_cap = 0;
     float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
     int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
+    int fuse_mlp = 0;                             // GVC_FUSE_MLP=1: c_fc + in-kernel exchange + mlp c_proj in ONE launch (measured: no faster)
+    unsigned long long* seam_gran = nullptr;      // [4d] {tag,value} granules of the in-kernel hidden-unit exchange
+    unsigned* seam_epoch = nullptr;               // launch counter of that exchange (device)
+    int* seam_err_host = nullptr;                 // pinned, device-visible: set when an in-kernel exchange timed out
+    int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int rows_decode_min = 7;                      // batches of at least this many streams decode on the MFMA rows path (0: never)
     float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
@@ -312,6 +317,13 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     if (getenv("GVC_PREFETCHER")) c->use_prefetcher = atoi(getenv("GVC_PREFETCHER"));
     if (getenv("GVC_PF_MASK")) c->pf_mask = atoi(getenv("GVC_PF_MASK"));
     if (getenv("GVC_FUSE_ATTN")) c->fuse_decode = atoi(getenv("GVC_FUSE_ATTN"));
+    if (getenv("GVC_FUSE_MLP")) c->fuse_mlp = atoi(getenv("GVC_FUSE_MLP"));
+    GVC_CHECK_HIP(hipMalloc((void**)&c->seam_gran, (size_t)4 * d * sizeof(unsigned long long) + 64));
+    GVC_CHECK_HIP(hipMemset(c->seam_gran, 0, (size_t)4 * d * sizeof(unsigned long long) + 64));
+    c->seam_epoch = reinterpret_cast<unsigned*>(c->seam_gran + 4 * d);
+    GVC_CHECK_HIP(hipHostMalloc((void**)&c->seam_err_host, sizeof(int), hipHostMallocMapped));
+    *c->seam_err_host = 0;
+    GVC_CHECK_HIP(hipHostGetDevicePointer((void**)&c->seam_err_dev, c->seam_err_host, 0));
     GVC_CHECK_HIP(hipMalloc((void**)&c->prog, sizeof(int32_t)));
     GVC_CHECK_HIP(hipMemset(c->prog, 0, sizeof(int32_t)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -334,6 +346,8 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->sched) hipFree(c->sched);
     if (c->prog) hipFree(c->prog);
+    if (c->seam_gran) hipFree(c->seam_gran);
+    if (c->seam_err_host) hipHostFree(c->seam_err_host);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
@@ -569,6 +583,12 @@ static bool fused_ok(const gvc_gpt* c, int B, int max_keys) {
     return c->fuse_decode && B == 1 && c->hd == 256 && c->dm.d_model % 16 == 0 && max_keys <= 8 * kFusedMaxKeys;
 }
 
+// one launch for the MLP block: needs every workgroup of the launch resident at once (d/4 workgroups of 1024 threads)
+static bool mlp_fused_ok(const gvc_gpt* c) {
+    const int d = c->dm.d_model;
+    return c->fuse_mlp && !c->bf16 && (d == 1024 || d == 256) && c->dm.n_head <= 16 && d / 4 <= c->n_cu;
+}
+
 static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
                         float* latent_out, int32_t* step_ctr, hipStream_t s, bool fused = false) {
     const int d = c->dm.d_model;
@@ -596,6 +616,21 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
             if (!prof_skip(c, 1)) {
                 hipLaunchKernelGGL((k_attn_proj<256>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
                 GVC_LAUNCH_CHECK();
+            }
+            if (mlp_fused_ok(c)) {
+                // [sum partials, LN2, c_fc, gelu] -> in-kernel exchange of the hidden units -> [mlp c_proj, residual]: one launch
+                MlpArgs M;
+                memset(&M, 0, sizeof(M));
+                M.x = c->x + (size_t)row0 * d; M.part2 = F.part2; M.pbias = ly.proj_b; M.ln_w = ly.ln2_w; M.ln_b = ly.ln2_b;
+                M.Wfc = ly.fc_w; M.bfc = ly.fc_b; M.Wp2 = ly.p2_w; M.bp2 = ly.p2_b; M.d = d; M.n_head = c->dm.n_head;
+                M.gran = c->seam_gran; M.epoch = c->seam_epoch; M.err = c->seam_err_dev; M.prog = c->prog_active;
+                if (c->dbg && c->dbg_n < 4096) M.dbg = c->dbg + 8 * (size_t)(c->dbg_n++);
+                if (!prof_skip(c, 3)) {
+                    if (d == 1024) hipLaunchKernelGGL((k_mlp_fused<8>), dim3(d / 4), dim3(1024), 0, s, M);
+                    else hipLaunchKernelGGL((k_mlp_fused<2>), dim3(d / 4), dim3(1024), 0, s, M);
+                    GVC_LAUNCH_CHECK();
+                }
+                continue;
             }
             A = base_args(c, slots, row0);
             A.Wt = ly.fc_w; A.Wt16 = ly.fc_h; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
@@ -668,6 +703,8 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
 
 static int check_ready(gvc_gpt* c) {
     GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
+    GVC_REQUIRE(!c->seam_err_host || *(volatile int*)c->seam_err_host == 0, GVC_ERR_HIP,
+                "an in-kernel exchange of a fused decode launch timed out (were all its workgroups resident?); unset GVC_FUSE_MLP");
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
                 gvc_gpt_missing_weights(c));
     return GVC_OK;

@@ -675,6 +675,196 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused MLP block of the one-stream decode step: [x' = x + attn c_proj bias + sum_h partials; LN2; c_fc; gelu_new]
+// -> in-kernel all-to-all of the 4d hidden units -> [mlp c_proj; x = x' + ...], ONE launch instead of two.
+//   * grid = d/4 workgroups (one per CU at d = 1024), all co-resident; 8 compute waves + 8 auxiliary waves.
+//   * the compute waves request BOTH weight slices of their workgroup at kernel start (16 hidden rows of c_fc and
+//     4 output rows of c_proj, 64 KiB each at d = 1024), so the c_proj stream runs underneath the c_fc phase and the
+//     exchange; nothing else is ever loaded by them (vmcnt retires in order per wave).
+//   * the auxiliary waves (no weight load outstanding) do the prologue and the exchange: every hidden unit is published
+//     as an 8-byte {tag, value} granule with an agent-scope store and gathered with agent-scope loads (the only
+//     hand-off that crosses XCDs: L2s are not coherent with each other); tag = launch epoch, kept in device memory
+//     and bumped by workgroup 0 at its end, after it has seen every workgroup's granules.
+//   * spins are bounded: a timeout raises *err (checked by the host) instead of hanging the GPU.
+// Workgroup barriers are bare s_barrier + lgkmcnt wait, so they do not drain the weight stream.
+// ---------------------------------------------------------------------------------------------
+struct MlpArgs {
+    float* x;                    // residual row of the stream [d], updated in place
+    const float* part2;          // [heads][d] per-head attention-projection partials (k_attn_proj)
+    const float* pbias;          // attn c_proj bias [d]
+    const float* ln_w; const float* ln_b;
+    const float* Wfc; const float* bfc;      // [4d][d], [4d]
+    const float* Wp2; const float* bp2;      // [d][4d], [d]
+    int d, n_head;
+    unsigned long long* gran;    // [4d] granules
+    unsigned* epoch;             // tag of the last launch that used `gran`
+    int* err;
+    int32_t* prog;
+    unsigned long long* dbg;     // null, or 8 timestamps: workgroup 0 {entry, LN2 ready, published, gathered}, last workgroup the same
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NI>        // d = 128 * NI
+__global__ __launch_bounds__(1024) void k_mlp_fused(const MlpArgs A) {
+    constexpr int D = 128 * NI, F = 4 * D, D4 = D / 4;
+    constexpr int WPR1 = D4 / 64;          // waves per c_fc row (K = d)
+    constexpr int WPR2 = D / 64;           // wave-partials per c_proj row (K = 4d): 2 * NI
+    __shared__ __attribute__((aligned(16))) float a_s[D];      // LN2(x')
+    __shared__ __attribute__((aligned(16))) float xp_s[D];     // x'
+    __shared__ __attribute__((aligned(16))) float h_s[F];      // gathered hidden units
+    __shared__ float red1[16][WPR1 > 0 ? WPR1 : 1];
+    __shared__ float red2[4][WPR2];
+    __shared__ float stat1[8], stat2[8];
+    __shared__ unsigned tag_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    if (wave < 8) {
+        // ---------------- compute waves: weights only ----------------
+        f32x4_nt w1[NI], w2[NI];
+        const f32x4_nt* p1 = reinterpret_cast<const f32x4_nt*>(A.Wfc + (size_t)wg * 16 * D) + tid;
+        const f32x4_nt* p2 = reinterpret_cast<const f32x4_nt*>(A.Wp2 + (size_t)wg * 4 * F) + tid;
+        // epilogue operands first (vmcnt retires in order: nothing may be requested behind the weight stream)
+        const float e_b1 = tid < 16 ? A.bfc[wg * 16 + tid] : 0.f;
+        const float e_b2 = tid < 4 ? A.bp2[wg * 4 + tid] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w1[i] = __builtin_nontemporal_load(p1 + i * 512);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();               // b0
+        lds_barrier();               // b0'
+        lds_barrier();               // b1: a_s ready
+        // the c_proj slice is requested only now: asked for at kernel start it doubles the queue in front of the prologue's
+        // small loads (they then return after ~6 us instead of ~2); from here it streams underneath phase 1 and the exchange
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w2[i] = __builtin_nontemporal_load(p2 + i * 512);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: 16 hidden rows of c_fc; float4 f = i*512 + tid sits in row f / D4 at column 4 * (f % D4)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = i * 512 + tid;
+            const float4 av = *reinterpret_cast<const float4*>(&a_s[(f % D4) * 4]);
+            float s = fmaf(w1[i].x, av.x, 0.f); s = fmaf(w1[i].y, av.y, s); s = fmaf(w1[i].z, av.z, s); s = fmaf(w1[i].w, av.w, s);
+            s = wave_sum(s);
+            if (lane == 0) red1[(i * 512 + wave * 64) / D4][((i * 512 + wave * 64) % D4) / 64] = s;
+        }
+        lds_barrier();               // b2: row partials ready
+        if (tid < 16) {
+            float v = e_b1;
+#pragma unroll
+            for (int q = 0; q < WPR1; ++q) v += red1[tid][q];
+            v = gelu_new(v);
+            const unsigned tag = tag_s;
+            __hip_atomic_store(A.gran + wg * 16 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();               // b3: h_s ready
+        // phase 2: 4 output rows of c_proj; float4 f sits in row f / D at column 4 * (f % D) of the 4d inputs
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = i * 512 + tid;
+            const float4 hv = *reinterpret_cast<const float4*>(&h_s[(f % D) * 4]);
+            float s = fmaf(w2[i].x, hv.x, 0.f); s = fmaf(w2[i].y, hv.y, s); s = fmaf(w2[i].z, hv.z, s); s = fmaf(w2[i].w, hv.w, s);
+            s = wave_sum(s);
+            if (lane == 0) red2[(i * 512 + wave * 64) / D][((i * 512 + wave * 64) % D) / 64] = s;
+        }
+        lds_barrier();               // b4
+        if (tid < 4) {
+            const int row = wg * 4 + tid;
+            float v = e_b2;
+#pragma unroll
+            for (int q = 0; q < WPR2; ++q) v += red2[tid][q];
+            A.x[row] = xp_s[row] + v;
+        }
+        return;
+    }
+    // ---------------- auxiliary waves: prologue + exchange ----------------
+    const int at = tid - 512;                     // 0..511
+    const int aw = wave - 8;                      // 0..7
+    const bool stamp = A.dbg && at == 0 && (wg == 0 || wg == (int)gridDim.x - 1);
+    unsigned long long* dbg = A.dbg + (wg == 0 ? 0 : 4);
+    if (stamp) dbg[0] = wall_clock64();
+    if (at == 0) {
+        if (A.prog && wg == 0) __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tag_s = *A.epoch + 1u;
+    }
+    // x' = x + pbias + sum_h part2[h]: thread `at` owns floats [4*at, 4*at+4) when 4*at < D
+    const bool has = at * 4 < D;
+    const int col = at * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), g4 = t, c4 = t;
+    if (has) {
+        t = *reinterpret_cast<const float4*>(A.x + col);
+        const float4 pb = *reinterpret_cast<const float4*>(A.pbias + col);
+        g4 = *reinterpret_cast<const float4*>(A.ln_w + col);
+        c4 = *reinterpret_cast<const float4*>(A.ln_b + col);
+        float4 ph[16];
+#pragma unroll
+        for (int h = 0; h < 16; ++h)
+            if (h < A.n_head) ph[h] = *reinterpret_cast<const float4*>(A.part2 + (size_t)h * D + col);
+        t.x += pb.x; t.y += pb.y; t.z += pb.z; t.w += pb.w;
+#pragma unroll
+        for (int h = 0; h < 16; ++h)
+            if (h < A.n_head) { t.x += ph[h].x; t.y += ph[h].y; t.z += ph[h].z; t.w += ph[h].w; }
+        *reinterpret_cast<float4*>(&xp_s[col]) = t;
+    }
+    constexpr int AWV = D / 256;                  // auxiliary waves that hold data (4 at d = 1024, 1 at d = 256)
+    const float inv_d = 1.0f / (float)D;
+    {
+        const float s1 = wave_sum((t.x + t.y) + (t.z + t.w));
+        if (lane == 0) stat1[aw] = s1;
+    }
+    lds_barrier();                   // b0
+    float mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < AWV; ++i) mean += stat1[i];
+    mean *= inv_d;
+    {
+        float s2 = 0.f;
+        if (has) {
+            const float a0 = t.x - mean, a1 = t.y - mean, a2 = t.z - mean, a3 = t.w - mean;
+            s2 = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        s2 = wave_sum(s2);
+        if (lane == 0) stat2[aw] = s2;
+    }
+    lds_barrier();                   // b0'
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < AWV; ++i) var += stat2[i];
+    const float rstd = 1.0f / sqrtf(var * inv_d + 1e-5f);
+    if (has) {
+        float4 o;
+        o.x = (t.x - mean) * rstd * g4.x + c4.x; o.y = (t.y - mean) * rstd * g4.y + c4.y;
+        o.z = (t.z - mean) * rstd * g4.z + c4.z; o.w = (t.w - mean) * rstd * g4.w + c4.w;
+        *reinterpret_cast<float4*>(&a_s[col]) = o;
+    }
+    lds_barrier();                   // b1
+    if (stamp) dbg[1] = wall_clock64();
+    lds_barrier();                   // b2 (the compute waves publish right after it)
+    if (stamp) dbg[2] = wall_clock64();
+    // gather the 4d hidden units of all workgroups
+    {
+        const unsigned tag = tag_s;
+        int spins = 0;
+        for (int idx = at; idx < F; idx += 512) {
+            unsigned long long g;
+            while (true) {
+                g = __hip_atomic_load(A.gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(g >> 32) == tag)) break;
+                if (++spins > 400000) { if (lane == 0) *A.err = 1; break; }      // ~0.1 s: not all workgroups resident?
+                __builtin_amdgcn_s_sleep(1);
+            }
+            h_s[idx] = __uint_as_float((unsigned)g);
+        }
+    }
+    if (stamp) dbg[3] = wall_clock64();
+    lds_barrier();                   // b3
+    lds_barrier();                   // b4
+    // every workgroup has published (this one gathered all of them) and read the epoch long ago: bump it for the next launch
+    if (wg == 0 && at == 0) *A.epoch = tag_s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Step-long weight prefetcher (one launch per decode step on a side stream, concurrent with the step graph).
 // One single-wave workgroup per CU polls the step's progress counter; when launch number `trigger` has
 // started it pulls the operand of a LATER launch from HBM into its XCD's L2 (chunk cb goes to a workgroup

@@ -345,3 +345,19 @@ def test_rows_mode_generate_matches_single_stream_tokens(gold):
     exp = np.tile(g["tokens"], (reps, 1))
     assert np.array_equal(toks.numpy(), exp), "rows-mode greedy ids differ from the reference"
     np.testing.assert_allclose(lats[:Bg, :, :32].numpy(), g["latents_slice"], atol=1e-4)
+
+
+def test_fused_mlp_launch_matches_reference(gold, monkeypatch):
+    """GVC_FUSE_MLP=1: c_fc -> in-kernel {tag,value} exchange of the hidden units -> mlp c_proj in one launch (an
+    experiment kept behind the flag: same tokens as the reference, no faster than two launches)"""
+    monkeypatch.setenv("GVC_FUSE_MLP", "1")
+    _cache.clear()
+    try:
+        for name, margs in (("gpt_tiny_b1", gcfg.TINY_MODEL_ARGS), ("gpt_full", gcfg.DEFAULT_MODEL_ARGS)):
+            g = gold(name)
+            if int(g["B"]) != 1:
+                continue
+            check_golden(g, margs)
+            _cache.clear()
+    finally:
+        _cache.clear()
