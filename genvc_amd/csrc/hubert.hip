@@ -20,7 +20,7 @@
 namespace gvc {
 
 typedef float hb_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kC0Chunk = 64;          // output frames per conv0 workgroup (= GroupNorm partial-statistics chunk)
+constexpr int kC0Chunk = 32;          // output frames per conv0 workgroup (= GroupNorm partial-statistics chunk)
 
 // Conv1d weight [Co][Ci][k] -> [Co][k*Ci] with column j*Ci + ci
 static __global__ void k_hb_repack_conv(const float* w, float* out, int Co, int Ci, int k) {
@@ -37,14 +37,15 @@ static __global__ void k_hb_repack_conv(const float* w, float* out, int Co, int 
 static __global__ __launch_bounds__(256) void k_hb_conv0(const float* wav, const float* w, float* y, float* part, int T,
                                                         int T0, int C, int k, int stride) {
     extern __shared__ float xs[];
-    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.z, chunk = blockIdx.x, tid = threadIdx.x;
     const int t0 = chunk * kC0Chunk;
     const int nt = min(kC0Chunk, T0 - t0);
     const int nx = (nt - 1) * stride + k;
     const float* src = wav + (size_t)b * T + (size_t)t0 * stride;
     for (int i = tid; i < nx; i += 256) xs[i] = src[i];
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    // grid (chunks, channel blocks of 256, batch): ~200 workgroups for a 1 s chunk
+    for (int c = blockIdx.y * 256 + tid; c < min(C, (int)(blockIdx.y + 1) * 256); c += 256) {
         float wr[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) wr[j] = j < k ? w[(size_t)c * k + j] : 0.f;
@@ -98,8 +99,12 @@ static __global__ void k_hb_gn_gelu(float* y, const float* stats, const float* g
 
 // dst[row] = LayerNorm(src[row]) * w + b; rows of d floats (d % 4 == 0, d <= 4096); row r of batch element
 // r / rows_per_batch lives at base + (r / rpb) * batch_stride + (r % rpb) * d
+// part != null: the row is first completed as src + bias + sum_s part[s][row] (raw K-split partials of the skinny GEMM);
+// dst_fm16 != null: the normalised row is also written in the FM16 fragment-major layout (A operand of the next GEMM)
 static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, long long src_bs, float* dst, long long dst_bs,
-                                                          int rpb, int d, const float* w, const float* b) {
+                                                          int rpb, int d, const float* w, const float* b,
+                                                          const float* part = nullptr, int SK = 0, const float* pbias = nullptr,
+                                                          int rows = 0, float* dst_fm16 = nullptr) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int bi = row / rpb, ri = row - bi * rpb;
@@ -111,6 +116,14 @@ static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, lon
     for (int i = 0; i < 4; ++i) {
         const int k = (i * 256 + tid) * 4;
         v[i] = k < d ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (part && k < d) {
+            const float4 b4 = *reinterpret_cast<const float4*>(pbias + k);
+            v[i].x += b4.x; v[i].y += b4.y; v[i].z += b4.z; v[i].w += b4.w;
+            for (int sidx = 0; sidx < SK; ++sidx) {
+                const float4 p4 = *reinterpret_cast<const float4*>(part + ((size_t)sidx * rows + row) * d + k);
+                v[i].x += p4.x; v[i].y += p4.y; v[i].z += p4.z; v[i].w += p4.w;
+            }
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float inv_d = 1.0f / (float)d;
@@ -135,6 +148,7 @@ static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, lon
             o.x = (v[i].x - mean) * rstd * gw.x + gb.x; o.y = (v[i].y - mean) * rstd * gw.y + gb.y;
             o.z = (v[i].z - mean) * rstd * gw.z + gb.z; o.w = (v[i].w - mean) * rstd * gw.w + gb.w;
             *reinterpret_cast<float4*>(orow + k) = o;
+            if (dst_fm16) *reinterpret_cast<float4*>(dst_fm16 + fm16_index(row, k, d)) = o;
         }
     }
 }
@@ -158,7 +172,7 @@ static __global__ void k_hb_zero_pad(float* buf, int C, int T, int front, int ba
 // B-operand layout of the second product when its k-step i is mapped to keys {key0 + 4g + i}.  The d index of the
 // first product is permuted (d = 16s + 4g + comp) and the row index of O^T is permuted (row m of tile mt <-> d = 4m + mt)
 // so that every fragment load is a float4.
-static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, float* out, int T, int E, float scale) {
+static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, float* out, int T, int E, float scale, int out_fm16) {
     __shared__ float sm[4][16], sl[4][16];
     __shared__ __attribute__((aligned(16))) float so[4][16][68];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -248,7 +262,8 @@ static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, f
         }
         const float inv = 1.0f / L;
         acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-        *reinterpret_cast<float4*>(out + ((size_t)b * T + q0 + qr) * E + h * 64 + dc) = acc;
+        if (out_fm16) *reinterpret_cast<float4*>(out + fm16_index(b * T + q0 + qr, h * 64 + dc, E)) = acc;
+        else *reinterpret_cast<float4*>(out + ((size_t)b * T + q0 + qr) * E + h * 64 + dc) = acc;
     }
 }
 
@@ -256,7 +271,7 @@ static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, f
 
 using namespace gvc;
 
-struct HbLin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct HbLin { float* w = nullptr; float* b = nullptr; int N = 0, K = 0; float* wf = nullptr; /* FM16 copy (skinny path) */ };
 struct HbLn { float* w = nullptr; float* b = nullptr; };
 struct HbLayer { HbLin qkv, out, fc1, fc2; HbLn ln1, ln2; };
 
@@ -279,6 +294,9 @@ struct gvc_hubert {
     std::map<long long, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
+    int skinny = 1;                               // GVC_HUBERT_SKINNY=0: always the tiled GEMM in the transformer
+    bool fm_ready = false;                        // FM16 copies match the bound weights
+    float *xf = nullptr, *af = nullptr, *hf = nullptr;   // FM16 activations of the skinny path (128 rows)
     std::vector<void*> allocs;
 };
 
@@ -354,7 +372,9 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
         if ((rc = hb_alloc_lin(c, L.fc1, D.ffn_dim, E))) break;
         if ((rc = hb_alloc_lin(c, L.fc2, E, D.ffn_dim))) break;
         if ((rc = hb_alloc_ln(c, L.ln1, E))) break;
-        rc = hb_alloc_ln(c, L.ln2, E);
+        if ((rc = hb_alloc_ln(c, L.ln2, E))) break;
+        for (HbLin* q : {&L.qkv, &L.out, &L.fc1, &L.fc2})
+            if ((rc = hb_alloc(c, &q->wf, (size_t)q->N * q->K))) break;
     }
     if (!rc) rc = hb_alloc_lin(c, c->fin, D.final_dim, E);
     // conv (1 + 2 for GroupNorm) + n_conv-1 + feature LN 2 + proj 2 + pos_conv 2 + encoder LN 2 + 16 per layer + final 2
@@ -369,10 +389,15 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
     if (!rc) rc = hb_alloc(c, &c->att, B * F * E);
     if (!rc) rc = hb_alloc(c, &c->qkv, B * F * 3 * E);
     if (!rc) rc = hb_alloc(c, &c->hbuf, B * F * D.ffn_dim);
+    if (!rc) rc = hb_alloc(c, &c->xf, (size_t)128 * E);
+    if (!rc) rc = hb_alloc(c, &c->af, (size_t)128 * E);
+    if (!rc) rc = hb_alloc(c, &c->hf, (size_t)128 * D.ffn_dim);
     c->work_cap = 16ll << 20;
     if (!rc) rc = hb_alloc(c, &c->work, (size_t)c->work_cap);
     if (!rc && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = GVC_ERR_HIP;
     if (getenv("GVC_HUBERT_GRAPH")) c->use_graph = atoi(getenv("GVC_HUBERT_GRAPH"));
+    if (getenv("GVC_HUBERT_SKINNY")) c->skinny = atoi(getenv("GVC_HUBERT_SKINNY"));
+    if (E % 128 != 0 || D.ffn_dim % 128 != 0) c->skinny = 0;
     if (rc) { gvc_hubert_destroy(c); return rc; }
     *out = c;
     return GVC_OK;
@@ -452,7 +477,7 @@ extern "C" int gvc_hubert_bind_weight(gvc_hubert* c, const char* name, const flo
         else if (sub.rfind("final_layer_norm.", 0) == 0) rc = ln(L.ln2, E);
         else known = false;
     } else known = false;
-    if (rc == GVC_OK && known) c->bound[n] = 1;
+    if (rc == GVC_OK && known) { c->bound[n] = 1; c->fm_ready = false; }
     return rc;
 }
 
@@ -532,13 +557,52 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
         G.e.resid = c->xp + b * xp_bs + (size_t)c->pad_front * E; G.e.ldr = E; G.e.resid_batch_stride = cg;
         if ((rc = launch_gemm_cap(G, D.pos_conv_groups, c->work_cap, s))) return rc;
     }
+    const bool skinny = c->skinny && rows <= 128;
+    if (skinny) {
+        // rows <= 128 (the 1 s streaming chunk: 49 frames): fragment-major skinny GEMMs, K-split partials folded into the
+        // post-LN kernels: 7 launches per layer, weights streamed once
+        hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
+                           c->enc_ln.w, c->enc_ln.b, (const float*)nullptr, 0, (const float*)nullptr, rows, c->xf);
+        GVC_LAUNCH_CHECK();
+        auto sk_gemm = [&](const HbLin& L, const float* A_fm, float* C, int act, int c_fm16, int SK, const float* resid = nullptr) {
+            GemmArgs G;
+            memset(&G, 0, sizeof(G));
+            G.A = A_fm; G.lda = L.K; G.Wt = L.wf; G.ldw = L.K; G.C = C; G.ldc = L.N; G.M = rows; G.N = L.N; G.K = L.K;
+            G.work = c->work;
+            if (SK == 1) { G.e.bias = L.b; G.e.act = act; G.e.c_fm16 = c_fm16; G.e.resid = resid; G.e.ldr = L.N; }
+            return launch_gemm_skinny(G, SK, c->work_cap, s);
+        };
+        auto post_ln = [&](const HbLin& L, const HbLn& N, int SK) {       // x = LN(x + linear) (+ FM16 copy)
+            if (SK > 1)
+                hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->x, (long long)F * E, c->x, (long long)F * E, F, E,
+                                   N.w, N.b, c->work, SK, L.b, rows, c->xf);
+            else
+                hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
+                                   N.w, N.b, (const float*)nullptr, 0, (const float*)nullptr, rows, c->xf);
+        };
+        const int sk_out = (E / 2) % 128 == 0 ? 2 : 1, sk_fc2 = (D.ffn_dim / 4) % 128 == 0 ? 4 : ((D.ffn_dim / 2) % 128 == 0 ? 2 : 1);
+        for (int l = 0; l < D.n_layers; ++l) {
+            const HbLayer& L = c->layers[l];
+            if ((rc = sk_gemm(L.qkv, c->xf, c->qkv, ACT_NONE, 0, 1))) return rc;
+            hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->af, F, E, 0.125f, 1);
+            GVC_LAUNCH_CHECK();
+            if ((rc = sk_gemm(L.out, c->af, c->tmp, ACT_NONE, 0, sk_out, c->x))) return rc;
+            post_ln(L.out, L.ln1, sk_out);
+            GVC_LAUNCH_CHECK();
+            if ((rc = sk_gemm(L.fc1, c->xf, c->hf, ACT_GELU_ERF, 1, 1))) return rc;
+            if ((rc = sk_gemm(L.fc2, c->hf, c->tmp, ACT_NONE, 0, sk_fc2, c->x))) return rc;
+            post_ln(L.fc2, L.ln2, sk_fc2);
+            GVC_LAUNCH_CHECK();
+        }
+        return GVC_OK;
+    }
     hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
                        c->enc_ln.w, c->enc_ln.b);
     GVC_LAUNCH_CHECK();
     for (int l = 0; l < D.n_layers; ++l) {
         const HbLayer& L = c->layers[l];
         if ((rc = hb_linear(c, L.qkv, c->x, c->qkv, rows, ACT_NONE, nullptr, s))) return rc;
-        hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->att, F, E, 0.125f);
+        hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->att, F, E, 0.125f, 0);
         GVC_LAUNCH_CHECK();
         if ((rc = hb_linear(c, L.out, c->att, c->tmp, rows, ACT_NONE, c->x, s))) return rc;
         hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
@@ -562,8 +626,16 @@ extern "C" int gvc_hubert_forward(gvc_hubert* c, const float* wav, int32_t B, in
     GVC_REQUIRE(B >= 1 && B <= D.max_batch && T <= D.max_samples && F >= 1, GVC_ERR_ARG,
                 "hubert: B=%d samples=%d outside capacity (%d, %d) or too short", B, T, D.max_batch, D.max_samples);
     hipStream_t s = (hipStream_t)sv;
+    if (c->skinny && !c->fm_ready) {
+        for (HbLayer& L : c->layers)
+            for (HbLin* q : {&L.qkv, &L.out, &L.fc1, &L.fc2}) {
+                hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, q->w, q->wf, q->N, q->K);
+                GVC_LAUNCH_CHECK();
+            }
+        c->fm_ready = true;
+    }
     const int T0 = hb_frames(D, T, 1), C0 = D.conv_dim[0], k0 = D.conv_kernel[0], s0 = D.conv_stride[0];
-    hipLaunchKernelGGL(k_hb_conv0, dim3(cdiv(T0, kC0Chunk), B), dim3(256), ((kC0Chunk - 1) * s0 + k0) * sizeof(float), s, wav,
+    hipLaunchKernelGGL(k_hb_conv0, dim3(cdiv(T0, kC0Chunk), cdiv(C0, 256), B), dim3(256), ((kC0Chunk - 1) * s0 + k0) * sizeof(float), s, wav,
                        c->conv0_w, c->act[0], c->part, T, T0, C0, k0, s0);
     GVC_LAUNCH_CHECK();
     int rc;
