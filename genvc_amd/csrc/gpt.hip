@@ -54,9 +54,11 @@ __global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const f
 }
 
 __global__ void k_embed_rows(float* x, const float* prefix_emb, int B, int T, int P, int d, const float* mel_emb,
-                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok) {
+                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok, int t_off) {
+    // rows [t_off, T) of every stream (t_off > 0: the leading rows are already in the KV cache)
     const int row = blockIdx.x;
-    const int b = row / T, t = row - b * T;
+    const int Tn = T - t_off;
+    const int b = row / Tn, t = row - b * Tn + t_off;
     float* dst = x + (size_t)row * d;
     if (t < P) {
         const float* src = prefix_emb + ((size_t)b * P + t) * d;
@@ -821,23 +823,35 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
 
 extern "C" int gvc_gpt_prefill(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
                                int32_t start_tok, float* logits_out, float* latent_out, gvc_stream sv) {
+    return gvc_gpt_prefill_cached(c, slots, B, prefix_emb, P, 0, start_tok, logits_out, latent_out, sv);
+}
+
+extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
+                                      int32_t n_cached, int32_t start_tok, float* logits_out, float* latent_out, gvc_stream sv) {
     int rc = check_ready(c);
     if (rc) return rc;
     const int T = P + 1, d = c->dm.d_model;
+    GVC_REQUIRE(n_cached >= 0 && n_cached <= P, GVC_ERR_ARG, "prefill: n_cached=%d outside [0,%d]", n_cached, P);
     GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "prefill: B=%d outside [1,%d]", B, c->dm.max_slots);
     GVC_REQUIRE(P >= 0 && B * T <= c->dm.max_rows, GVC_ERR_ARG, "prefill: %d rows exceed max_rows %d", B * T, c->dm.max_rows);
     GVC_REQUIRE(T < c->dm.max_seq, GVC_ERR_ARG, "prefill: %d rows exceed max_seq %d", T, c->dm.max_seq);
     hipStream_t s = (hipStream_t)sv;
     if (!logits_out) logits_out = c->logits;      // staging of the generation loop
     if (!latent_out) latent_out = c->latent;
-    hipLaunchKernelGGL(k_embed_rows, dim3(B * T), dim3(256), 0, s, c->x, prefix_emb, B, T, P, d, c->mel_emb, c->mel_pos,
-                       (const int32_t*)nullptr, 0, start_tok, start_tok);
+    hipLaunchKernelGGL(k_embed_rows, dim3(B * (T - n_cached)), dim3(256), 0, s, c->x, prefix_emb, B, T, P, d, c->mel_emb, c->mel_pos,
+                       (const int32_t*)nullptr, 0, start_tok, start_tok, n_cached);
     GVC_LAUNCH_CHECK();
-    if ((rc = run_rows(c, slots, B, T, s))) return rc;
+    const int Tn = T - n_cached;
+    if (n_cached > 0) {
+        // the rows continue the cached prefix: K/V go to positions n_cached.., attention sees [0, n_cached + t]
+        hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, n_cached, 0);
+        GVC_LAUNCH_CHECK();
+        if ((rc = run_rows(c, slots, B, Tn, s, c->st.seq_len))) return rc;
+    } else if ((rc = run_rows(c, slots, B, T, s))) return rc;
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         GemvArgs A = base_args(c, slots + g, 0);
-        A.x = c->x + (size_t)g * T * d; A.x_stride = T; A.x_off = T - 1;
+        A.x = c->x + (size_t)g * Tn * d; A.x_stride = Tn; A.x_off = Tn - 1;
         A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
         A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
         A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 0;
@@ -859,7 +873,7 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
     GVC_REQUIRE(T < c->dm.max_seq && n + 5 <= c->dm.max_mel_pos, GVC_ERR_ARG, "latents: sequence too long");
     hipStream_t s = (hipStream_t)sv;
     hipLaunchKernelGGL(k_embed_rows, dim3(B * T), dim3(256), 0, s, c->x, prefix_emb, B, T, P, d, c->mel_emb, c->mel_pos,
-                       gen_codes, n, start_tok, stop_tok);
+                       gen_codes, n, start_tok, stop_tok, 0);
     GVC_LAUNCH_CHECK();
     if ((rc = run_rows(c, slots, B, T, s))) return rc;
     hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(B * T, 4)), dim3(256), 0, s, c->x, c->a, B * T, d, c->lnf_w, c->lnf_b,

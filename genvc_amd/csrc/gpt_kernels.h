@@ -932,7 +932,7 @@ __global__ void k_ln_rows(const float* src, float* dst, int rows, int d, const f
 // build GPT input rows: t < P -> prefix_emb[b][t]; else mel_embedding[tok] + mel_pos[t - P]
 //   tok: t == P -> start_tok; 1 <= t-P <= n -> codes[b][t-P-1]; beyond -> stop_tok
 __global__ void k_embed_rows(float* x, const float* prefix_emb, int B, int T, int P, int d, const float* mel_emb,
-                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok);
+                             const float* mel_pos, const int32_t* codes, int n, int start_tok, int stop_tok, int t_off);
 // prefix rows of GPT.compute_embeddings
 __global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const int32_t* codes, int B, int Tc,
                               int d, const float* text_emb, const float* text_pos, int start_text,

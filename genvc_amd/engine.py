@@ -71,14 +71,16 @@ class GptEngine:
                                               ptr(out), stream()), "prefix_embeddings")
         return out
 
-    def prefill(self, slots, prefix_emb, want_outputs=True):
+    def prefill(self, slots, prefix_emb, want_outputs=True, n_cached=0):
+        """n_cached > 0: the first n_cached rows of the prefix (the conditioning latents) are already in the slots' KV
+        cache from an earlier prefill with the same leading rows -- only the rest is computed (bit-identical results)"""
         B, P, _ = prefix_emb.shape
         logits = latent = None
         if want_outputs:
             logits = torch.empty(B, self.V, device=prefix_emb.device, dtype=torch.float32)
             latent = torch.empty(B, self.d, device=prefix_emb.device, dtype=torch.float32)
-        check(lib().gvc_gpt_prefill(self._h, ptr(_i32(slots)), B, ptr(_f32(prefix_emb)), P,
-                                    self.dims["start_audio_token"], ptr(logits), ptr(latent), stream()), "prefill")
+        check(lib().gvc_gpt_prefill_cached(self._h, ptr(_i32(slots)), B, ptr(_f32(prefix_emb)), P, int(n_cached),
+                                           self.dims["start_audio_token"], ptr(logits), ptr(latent), stream()), "prefill")
         return logits, latent
 
     def decode_step(self, slots, tok, logits=None, latent=None):

@@ -97,13 +97,15 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
     src_wav = src_wav.to(m.device)
     seg = int(seg_len * m.content_sample_rate)
     cond_latent = m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
+    cached = 0          # prefix caching: after the first segment the conditioning rows are already in the KV cache
     for src_seg in segments(src_wav, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
         codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         fake = m.gpt.compute_embeddings(cond_latent, codes)
         gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,
                                   output_hidden_states=True, stream_group=max(stream_chunk_size, 1),
-                                  **_sampling_kwargs(m))
+                                  cached_cond_rows=cached, **_sampling_kwargs(m))
+        cached = cond_latent.shape[1]
         last_tokens, all_latents = [], []
         is_end = False
         while not is_end:
@@ -159,13 +161,15 @@ def synthesize_streams_streaming(genVC_mdl, src_wavs, tgt_audios, seg_len=1.0, s
     stop = m.gpt.stop_audio_token
     prev, overlap = [None] * B, [None] * B
     pred, tokens = [[] for _ in range(B)], [[] for _ in range(B)]
+    cached = 0
     for src_seg in segments(src_wavs, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
         codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         fake = m.gpt.compute_embeddings(cond_latent, codes)
         gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,
                                   output_hidden_states=True, stream_group=max(stream_chunk_size, 1),
-                                  **_sampling_kwargs(m))
+                                  cached_cond_rows=cached, **_sampling_kwargs(m))
+        cached = cond_latent.shape[1]
         alive = [True] * B                        # a stream stops with its own EOS step (latent included, :189-196)
         g_tok, g_lat = [], []
         is_end = False

@@ -163,7 +163,9 @@ class GPT(nn.Module):
         samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
                     top_p=kw.get("top_p", 1.0), top_k=kw.get("top_k", 0) if kw.get("do_sample", True) else 1)
         st["params"] = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
-        self.engine.prefill(slots, self._prefix, want_outputs=False)
+        # `cached_cond_rows` (extension): the leading rows of the prefix -- the conditioning latents, identical for every
+        # segment of an utterance -- are still in the KV cache from the previous segment's prefill of these slots
+        self.engine.prefill(slots, self._prefix, want_outputs=False, n_cached=int(kw.get("cached_cond_rows", 0)))
         return st
 
     def _advance(self, st, n):

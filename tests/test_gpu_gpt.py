@@ -361,3 +361,32 @@ def test_fused_mlp_launch_matches_reference(gold, monkeypatch):
             _cache.clear()
     finally:
         _cache.clear()
+
+
+@pytest.mark.parametrize("margs", [gcfg.TINY_MODEL_ARGS, gcfg.DEFAULT_MODEL_ARGS], ids=["tiny", "full"])
+def test_prefix_cache_prefill_is_bit_identical(margs):
+    """gvc_gpt_prefill_cached: with the 32 conditioning rows of an earlier segment still in the KV cache, a new segment's
+    prefill computes only its text rows + start token, and everything downstream is bit-identical to a full prefill"""
+    dims, w, eng = setup(margs, 3)
+    dev = "cuda"
+    B = 2
+    cond = synth.uniform(91, "cond_latents", (B, 32, dims["d_model"]), 1.0).to(dev)
+    codes_a = synth.integers(91, "codes_a", (B, 13), 256).to(dev).int()
+    codes_b = synth.integers(92, "codes_b", (B, 17), 256).to(dev).int()          # the next segment may have another length
+    s_cached = torch.tensor([0, 1], device=dev, dtype=torch.int32)
+    s_fresh = torch.tensor([2, 3], device=dev, dtype=torch.int32)
+    eng.prefill(s_cached, eng.prefix_embeddings(cond, codes_a), want_outputs=False)       # segment A fills the cache
+    tok = torch.tensor([5, 900], device=dev, dtype=torch.int32)
+    for _ in range(3):
+        eng.decode_step(s_cached, tok)                                                     # ... and decodes a little
+    pb = eng.prefix_embeddings(cond, codes_b)
+    lg_c, lat_c = eng.prefill(s_cached, pb, n_cached=32)
+    lg_f, lat_f = eng.prefill(s_fresh, pb)
+    assert torch.equal(lg_c, lg_f) and torch.equal(lat_c, lat_f)
+    for j in range(4):
+        a = eng.decode_step(s_cached, tok)
+        b = eng.decode_step(s_fresh, tok)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), j
+    from genvc_amd._lib import GenvcHipError
+    with pytest.raises(GenvcHipError):
+        eng.prefill(s_cached, pb, n_cached=pb.shape[1] + 1)
