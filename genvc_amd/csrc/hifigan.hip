@@ -109,6 +109,89 @@ __global__ void k_conv_post_tanh(const float* x, const float* w, const float* bi
     wav[(size_t)b * T + t] = tanhf(acc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ResBlock conv of the last two stages (C = 32 or 64 channels in and out, k <= 7 taps, dilation <= 12): the whole
+// K = k*C extent is small, so instead of the tiled GEMM's k-loop (one global->LDS->sync round trip per 32 columns:
+// 11-22 us for 0.1 GFLOP) a workgroup stages EVERYTHING it needs in one round trip -- the 32 + (k-1)*dil input rows of
+// its 32 output frames (leaky-ReLU applied while staging) and the full [C][k*C] weight matrix -- and then runs the
+// implicit im2col straight out of LDS.  A workgroup owns 32 frames x 32 output channels; its 4 (C = 32) or 8 (C = 64)
+// waves split the (tap, 8-channel group) steps of the reduction and combine through LDS; bias / residual(s) / scale in
+// the epilogue.  grid (T/32, C/32, B).
+// ---------------------------------------------------------------------------------------------
+struct ConvSmallArgs {
+    const float* x; float* y;            // padded time-major [B][T + 2*kHfPad][C]
+    const float* w; const float* b;      // [C][k*C] (column tap*C + ci), [C]
+    const float* resid; const float* resid2;
+    int T, k, dil;
+    float slope, out_scale;
+};
+
+typedef float hf_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
+    // grid (T/32, C/32, B): a workgroup owns 32 frames x one 32-channel tile of the outputs; NW waves split the reduction
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int XS = C + 4, NTH = NW * 64;
+    const int K = A.k * C, WS = K + 4;
+    const int R = 32 + (A.k - 1) * A.dil;
+    float* Xs = lds;                       // [R][XS]
+    float* Ws = lds + (size_t)R * XS;      // [32][WS]
+    float* red = lds;                      // [NW][16][64] after the MFMA loop (aliases Xs/Ws)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, b = blockIdx.z;
+    const int pad = A.dil * (A.k - 1) / 2;
+    const size_t bs = (size_t)(A.T + 2 * kHfPad) * C;
+    const float* xb = A.x + b * bs + (size_t)(kHfPad + t0 - pad) * C;
+    for (int i = tid; i < R * (C / 4); i += NTH) {
+        const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
+        float4 v = *reinterpret_cast<const float4*>(xb + (size_t)r * C + c4);
+        v.x = v.x > 0.f ? v.x : v.x * A.slope; v.y = v.y > 0.f ? v.y : v.y * A.slope;
+        v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
+        *reinterpret_cast<float4*>(&Xs[r * XS + c4]) = v;
+    }
+    for (int i = tid; i < 32 * (K / 4); i += NTH) {
+        const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
+        *reinterpret_cast<float4*>(&Ws[n * WS + k4]) = *reinterpret_cast<const float4*>(A.w + (size_t)(n0 + n) * K + k4);
+    }
+    __syncthreads();
+    hf_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int m = lane & 31, half = lane >> 5;
+    const int steps = A.k * (C / 8);
+    for (int it = wave; it < steps; it += NW) {
+        const int tap = it / (C / 8), q = it - tap * (C / 8);
+        const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(m + tap * A.dil) * XS + 8 * q + 4 * half]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&Ws[m * WS + tap * C + 8 * q + 4 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    __syncthreads();                      // everyone is done reading Xs / Ws: the region becomes the reduction buffer
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    // thread (wave, lane) finishes accumulator registers wave*16/NW .. of the tile
+    constexpr int RPW = 16 / NW;
+    const size_t ob = b * bs + (size_t)(kHfPad + t0) * C;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * 16 + r) * 64 + lane];
+        const int mo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = n0 + (lane & 31);
+        const size_t o = ob + (size_t)mo * C + n;
+        v += A.b[n];
+        if (A.resid) v += A.resid[o];
+        if (A.resid2) v += A.resid2[o];
+        if (A.out_scale != 0.f) v *= A.out_scale;
+        A.y[o] = v;
+    }
+}
+
 }  // namespace gvc
 
 using namespace gvc;
@@ -135,6 +218,7 @@ struct gvc_hifigan {
     std::map<long long, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
+    int small_conv = 1;                      // GVC_VOCODER_SMALL_CONV=0: ResBlock convs of the last stages through the tiled GEMM
 };
 
 static int halloc(gvc_hifigan* c, float** p, size_t n) {
@@ -200,6 +284,10 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     c->n_expected = 2 * (2 + D.n_ups + 2 * D.n_ups * D.n_kernels);
     if (rc) { gvc_hifigan_destroy(c); return rc; }
     if (getenv("GVC_VOCODER_GRAPH")) c->use_graph = atoi(getenv("GVC_VOCODER_GRAPH"));
+    if (getenv("GVC_VOCODER_SMALL_CONV")) c->small_conv = atoi(getenv("GVC_VOCODER_SMALL_CONV"));
+    // up to ~150 KB of dynamic LDS (64 channels, 7 taps): raise the per-kernel limit once, outside any capture
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     *out = c;
     return GVC_OK;
@@ -273,8 +361,25 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
 extern "C" int gvc_hifigan_missing_weights(gvc_hifigan* c) { return c ? c->n_expected - (int)c->bound.size() : -1; }
 
 // out rows [PAD, PAD+T) = epilogue(conv(lrelu?(src)))
+static size_t conv_small_lds(const HfConv& w) {
+    const size_t R = 32 + (size_t)(w.k - 1) * w.dil, K = (size_t)w.k * w.Ci;
+    const size_t stage = R * (w.Ci + 4) + (size_t)32 * (K + 4), red = (size_t)8 * 16 * 64;
+    return (stage > red ? stage : red) * sizeof(float);
+}
+
 static int hf_conv(gvc_hifigan* c, const HfConv& w, const float* src, float* dst, int T, int B, float a_slope,
                    const float* resid, const float* resid2, float out_scale, hipStream_t s) {
+    if (c->small_conv && w.Ci == w.Co && (w.Ci == 32 || w.Ci == 64) && T % 32 == 0 && a_slope != 0.f &&
+        conv_small_lds(w) <= 160 * 1024) {
+        ConvSmallArgs A;
+        A.x = src; A.y = dst; A.w = w.w; A.b = w.b; A.resid = resid; A.resid2 = resid2; A.T = T; A.k = w.k; A.dil = w.dil;
+        A.slope = a_slope; A.out_scale = out_scale;
+        const size_t lds = conv_small_lds(w);
+        if (w.Ci == 32) hipLaunchKernelGGL((k_conv_small<32, 4>), dim3(T / 32, 1, B), dim3(256), lds, s, A);
+        else hipLaunchKernelGGL((k_conv_small<64, 8>), dim3(T / 32, 2, B), dim3(512), lds, s, A);
+        GVC_LAUNCH_CHECK();
+        return GVC_OK;
+    }
     GemmArgs G;
     memset(&G, 0, sizeof(G));
     const int pad = w.dil * (w.k - 1) / 2;
