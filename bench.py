@@ -232,13 +232,27 @@ def main():
         # HIP events on the launch stream (gvc_gpt_time_kernel); mean per launch, launch boundary included
         S = wl.P + 1 + STEPS_PER_CHUNK // 2
         tok = torch.zeros(1, device=device, dtype=torch.int32)
+        s1 = wl.slots[:1].contiguous()
+        # whole step and the step without each class, replayed back to back between two HIP events on the launch stream:
+        # in-situ cost of a class = (whole - without) / launches.  (Single-kernel event pairs are useless at 5 us; a class
+        # launched alone re-reads its own stale inputs from L2 and looks 5-12 % faster than rocprofv3 sees it in the step.)
+        def fresh():
+            wl.eng.prefill(s1, wl.eng.prefix_embeddings(wl.model.get_gpt_cond_latents(wl.ref[0], 24000),
+                                                        torch.zeros(1, wl.Tc, device=device, dtype=torch.int32)), want_outputs=False)
+        reps = 40
+        fresh()
+        whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)
         kern = []
         for which in range(6):
-            avg, n = wl.eng.time_kernel(which, wl.slots[:1].contiguous(), tok, 128 if which == 5 else 32)
             per_step = 1 if which == 5 else wl.dims["n_layer"]
-            kern.append({"kernel": KERNEL_NAMES[which], "avg_us": avg, "launches_timed": n, "launches_per_step": per_step,
-                         "bytes": kernel_bytes(wl.dims, which, S)})
-        kern = [k for k in kern if k["launches_timed"] > 0]
+            fresh()
+            iso, n = wl.eng.time_kernel(which, s1, tok, 128 if which == 5 else 32)
+            if n == 0:
+                continue
+            fresh()
+            without_us, _ = wl.eng.time_kernel(16 + which, s1, tok, reps)
+            kern.append({"kernel": KERNEL_NAMES[which], "avg_us": (whole_us - without_us) / per_step, "avg_us_launched_alone": iso,
+                         "launches_per_step": per_step, "bytes": kernel_bytes(wl.dims, which, S)})
         # dominant = the weight-streaming GEMV with the largest share of the step (the fused attention launch is
         # L2/latency-bound, not an HBM stream, so it is listed but not used as the roofline kernel)
         cand = [i for i, k in enumerate(kern) if "gemv" in k["kernel"] and "head" not in k["kernel"]]
@@ -268,7 +282,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": kern[dom]["bytes"], "avg_us": kern[dom]["avg_us"],
-                         "decode_step_us": sum(k["avg_us"] * k["launches_per_step"] for k in kern)},
+                         "decode_step_us": whole_us},
             "kernels": kern,
         }
         if world == 1 and not args.no_cpu_baseline:

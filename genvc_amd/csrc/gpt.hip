@@ -214,6 +214,7 @@ struct gvc_gpt {
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;   // 2*B + fused -> step graph
     int prof_only = -1;               // gvc_gpt_time_kernel(): launch only this kernel class
+    int prof_skip_one = -1;           // ... or every class except this one
     // step-long prefetcher (graph path only)
     int use_prefetcher = 0;           // measured slower on MI355X; GVC_PREFETCHER=1 enables
     PrefetchEntry* sched = nullptr;
@@ -577,7 +578,9 @@ static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
 
 // one decode step for a group of <= 8 streams whose scratch rows start at row0
 // gvc_gpt_time_kernel(): when prof_only >= 0 only that kernel class of the step is launched
-static inline bool prof_skip(const gvc_gpt* c, int which) { return c->prof_only >= 0 && c->prof_only != which; }
+static inline bool prof_skip(const gvc_gpt* c, int which) {
+    return (c->prof_only >= 0 && c->prof_only != which) || c->prof_skip_one == which;
+}
 
 // can the fused attention + c_proj launch serve this call?  one stream, head_dim 256, and the caller
 // guarantees at most 8 * kFusedMaxKeys cached positions for the whole run (gvc_gpt_generate: ids_stride)
@@ -1007,7 +1010,11 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
                                    int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream sv) {
     int rc = check_ready(c);
     if (rc) return rc;
-    GVC_REQUIRE(which >= 0 && which <= 5 && B >= 1 && B <= 8 && n_steps >= 1 && avg_us, GVC_ERR_ARG,
+    // which 0..5: that class alone; 6: the whole step; 16 + X: the whole step WITHOUT class X (in-situ cost of X =
+    // (whole - without) / launches: the class then runs behind its real predecessor, whose output it has to fetch from
+    // the other XCDs, instead of re-reading its own stale inputs from L2)
+    const bool whole = which == 6 || (which >= 16 && which <= 21);
+    GVC_REQUIRE(((which >= 0 && which <= 5) || whole) && B >= 1 && B <= 8 && n_steps >= 1 && avg_us, GVC_ERR_ARG,
                 "time_kernel: bad argument");
     hipStream_t s = (hipStream_t)sv;
     hipEvent_t e0, e1;
@@ -1016,7 +1023,8 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     // one pass over the layers with only this kernel class is captured into a graph (eager launches of ~5 us
     // kernels are host-bound) and replayed n_steps times between two events on the caller's stream
     const bool fused = fused_ok(c, B, 0);       // the short-context variant bench.py's workload runs
-    c->prof_only = which;
+    c->prof_only = whole ? -1 : which;
+    c->prof_skip_one = which >= 16 ? which - 16 : -1;
     hipGraph_t graph = nullptr;
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
@@ -1025,6 +1033,7 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
         e = hipStreamEndCapture(c->cap_stream, &graph);
     }
     c->prof_only = -1;
+    c->prof_skip_one = -1;
     if (e == hipSuccess && rc == GVC_OK) e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
     if (graph) (void)hipGraphDestroy(graph);
     float ms = 0.f;
@@ -1041,7 +1050,7 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     GVC_CHECK_HIP(e);
-    const int n = (which == 5 ? 1 : (fused && which == 2 ? 0 : c->dm.n_layer)) * n_steps;
+    const int n = (whole ? 1 : (which == 5 ? 1 : (fused && which == 2 ? 0 : c->dm.n_layer))) * n_steps;
     *avg_us = n ? ms * 1000.0f / (float)n : 0.f;
     if (n_launches) *n_launches = n;
     return GVC_OK;

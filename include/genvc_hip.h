@@ -159,6 +159,9 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head
  * GEMV) for every layer, n_steps times back to back on the stream between two hipEvents, and returns the
  * mean microseconds per launch (same-stream launch boundary included) and the number of launches.
+ * which = 6: the whole decode step (sampler excluded); which = 16 + X: the whole step WITHOUT class X, so that
+ * (whole - without) / launches_per_step is the IN-SITU cost of class X (behind its real predecessor, as rocprofv3
+ * sees it); both return microseconds per step.
  * Synchronises the stream; leaves the slots' caches in an undefined state (reset or prefill afterwards). */
 int gvc_gpt_time_kernel(gvc_gpt* ctx, int32_t which, const int32_t* slots, int32_t B, const int32_t* tok_in,
                         int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream s);
