@@ -115,6 +115,18 @@ __global__ void k_embed_decode_rows(float* x, const int32_t* tok, const int32_t*
     }
 }
 
+// The generation loop's staging buffers (next-step logits and latent) are indexed by the position of a stream in the CALL;
+// between calls they are parked per SLOT, so that consecutive calls may batch different sets of streams (streaming.py)
+__global__ void k_stage_rows(float* stage, float* store, const int32_t* slots, int n, int to_store) {
+    const int b = blockIdx.x;
+    float* a = stage + (size_t)b * n;
+    float* s = store + (size_t)slots[b] * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (to_store) s[i] = a[i];
+        else a[i] = s[i];
+    }
+}
+
 __global__ void k_set_state(GptState st, const int32_t* slots, int B, int seq_len, int mel_pos) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
@@ -206,7 +218,8 @@ struct gvc_gpt {
     int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int rows_decode_min = 7;                      // batches of at least this many streams decode on the MFMA rows path (0: never)
-    float *logits = nullptr, *latent = nullptr;   // generate(): [slots][V], [slots][d]
+    float *logits = nullptr, *latent = nullptr;             // staging of the generation loop, indexed by position in the call
+    float *slot_logits = nullptr, *slot_latent = nullptr;   // ... parked per slot between calls   // generate(): [slots][V], [slots][d]
     int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step
     GptState st;
     int32_t *tok_buf = nullptr, *step_ctr = nullptr;
@@ -303,6 +316,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
         (rc = alloc_f(&c->part, (size_t)D.max_slots * D.n_head * kAttnChunks * (hd + 4))) ||
         (rc = alloc_f(&c->work, (size_t)c->work_cap)) || (rc = alloc_f(&c->logits, (size_t)D.max_slots * V)) ||
         (rc = alloc_f(&c->latent, (size_t)D.max_slots * d)) || (rc = alloc_f(&c->x2, (size_t)D.max_slots * d)) ||
+        (rc = alloc_f(&c->slot_logits, (size_t)D.max_slots * V)) || (rc = alloc_f(&c->slot_latent, (size_t)D.max_slots * d)) ||
         (rc = alloc_f(&c->part2, (size_t)D.max_slots * D.n_head * d))) {
         gvc_gpt_destroy(c);
         return rc;
@@ -352,7 +366,7 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->seam_gran) hipFree(c->seam_gran);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
-                    (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
+                    (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->slot_logits, (void*)c->slot_latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
         if (p) hipFree(p);
     delete c;
@@ -862,6 +876,11 @@ extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t 
     }
     hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, T, 1);
     GVC_LAUNCH_CHECK();
+    if (logits_out == c->logits && latent_out == c->latent) {       // generation staging: park it per slot
+        hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
+        hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, d, 1);
+        GVC_LAUNCH_CHECK();
+    }
     return GVC_OK;
 }
 
@@ -970,6 +989,8 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     sc.latents_out = latents_out; sc.lat_stride = lat_stride; sc.d = c->dm.d_model;
     GVC_CHECK_HIP(hipMemsetAsync(c->step_ctr, 0, sizeof(int32_t), s));
     hipLaunchKernelGGL(k_set_gen_call, dim3(1), dim3(64), 0, s, c->gen_call, sc, slots, B);
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 0);
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 0);
     GVC_LAUNCH_CHECK();
     // ids_stride bounds the cached positions of this run (prefix + 1 + every step the caller will ask for)
     const bool fused = fused_ok(c, B, ids_stride);
@@ -993,6 +1014,9 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
         }
         GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
     }
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 1);
+    GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
 

@@ -1,0 +1,154 @@
+"""Streaming sessions: persistent per-stream KV slots and a step scheduler.
+
+The reference converts one utterance per call and re-runs everything per segment (inference_utils.py:135-217).  A
+deployment has several live streams whose segments arrive at different times.  `StreamSessions` keeps one KV-cache slot
+per open stream and, at every `step()`, batches whatever the open streams need next:
+
+  * streams with a queued source segment that are not decoding: ContentVec -> DVAE/VQ -> prefix embeddings -> prefill,
+    batched over the streams whose segment has the same length (the conditioning rows of a stream stay in its slot after
+    its first segment: `gvc_gpt_prefill_cached`);
+  * streams that are decoding: ONE `gvc_gpt_generate` call of `group` steps over all of them, whatever their positions
+    (per-slot cache lengths live on the device; the MFMA rows path from 7 streams up);
+  * the vocoder for the token groups that came out, batched over equal group lengths, cross-faded per stream exactly as
+    `handle_chunks` does inside `synthesize_utt_streaming`.
+
+Each stream produces the tokens and the waveform of `synthesize_utt_streaming(model, its_source, its_reference,
+seg_len)` at top_k = 1.  With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in
+the call, not in the utterance.
+"""
+import torch
+
+from .inference.inference_utils import _sampling_kwargs, _vocode, handle_chunks
+from .engine import sample_params
+
+
+class _Session:
+    def __init__(self, slot, cond):
+        self.slot, self.cond = slot, cond
+        self.queue = []            # pending source segments [1, n]
+        self.decoding = False
+        self.prefilled = False     # the conditioning rows are in the slot's cache
+        self.done = 0              # tokens generated for the current segment
+        self.prev = self.overlap = None
+        self.tokens = []           # per segment: int64 [1, n]
+
+
+class StreamSessions:
+    def __init__(self, model, max_sessions=8, group=8):
+        m = self.m = model
+        g = m.gpt
+        g._need_engine()
+        self.eng = g.engine
+        self.group = group
+        self.max_new = g.max_gen_mel_tokens
+        self.free = list(range(max_sessions))
+        self.sessions = {}
+        self._next_id = 0
+        dev = m.device
+        kw = _sampling_kwargs(m)
+        samp = dict(repetition_penalty=kw["repetition_penalty"], temperature=kw["temperature"], top_p=kw["top_p"], top_k=kw["top_k"])
+        self.params = sample_params(samp, g.num_audio_tokens, g.stop_audio_token, 0)
+        self.calls = 0
+        self.stop = g.stop_audio_token
+        # per-slot history of input ids (fake prefix + generated), as wide as the longest run
+        self.width = 32 + g.max_text_tokens + 2 + 1 + self.max_new + 8
+        self.ids = torch.ones(max_sessions, self.width, device=dev, dtype=torch.int32)
+        self.ids_len = torch.zeros(max_sessions, device=dev, dtype=torch.int32)
+        self.finished = torch.zeros(max_sessions, device=dev, dtype=torch.int32)
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def open(self, ref_audio):
+        """ref_audio [1, n] at the model rate -> session id"""
+        if not self.free:
+            raise RuntimeError("no free stream slot")
+        cond = self.m.get_gpt_cond_latents(ref_audio.to(self.m.device), self.m.config.audio.sample_rate)
+        sid = self._next_id
+        self._next_id += 1
+        self.sessions[sid] = _Session(self.free.pop(0), cond)
+        return sid
+
+    def push(self, sid, src_segment):
+        """queue one source segment [1, n] at 16 kHz (what `segments()` yields for a whole utterance)"""
+        self.sessions[sid].queue.append(src_segment.to(self.m.device))
+
+    def close(self, sid):
+        s = self.sessions.pop(sid)
+        self.free.append(s.slot)
+        return s.tokens
+
+    def idle(self):
+        return all(not s.decoding and not s.queue for s in self.sessions.values())
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def step(self):
+        """advance every open stream by one scheduling step; returns {sid: [wav chunks emitted now]}"""
+        m, eng, dev = self.m, self.eng, self.m.device
+        out = {}
+        # 1. segments that can start: batch by (segment length, cached or not)
+        starts = {}
+        for sid, s in self.sessions.items():
+            if not s.decoding and s.queue:
+                starts.setdefault((s.queue[0].shape[-1], s.prefilled), []).append(sid)
+        for (n, cached), sids in starts.items():
+            ss = [self.sessions[i] for i in sids]
+            wav = torch.cat([s.queue.pop(0) for s in ss], 0)
+            feat = m.content_extractor.extract_content_features(wav)
+            codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+            cond = torch.cat([s.cond for s in ss], 0)
+            prefix = eng.prefix_embeddings(cond.to(torch.float32).contiguous(), codes.to(torch.int32).contiguous())
+            P = prefix.shape[1]
+            slots = torch.tensor([s.slot for s in ss], device=dev, dtype=torch.int32)
+            eng.prefill(slots, prefix, want_outputs=False, n_cached=cond.shape[1] if cached else 0)
+            idx = slots.long()
+            self.ids[idx] = 1
+            self.ids[idx, P] = m.gpt.start_audio_token
+            self.ids_len[idx] = P + 1
+            self.finished[idx] = 0
+            for s in ss:
+                s.decoding, s.prefilled, s.done, s.p1 = True, True, 0, P + 1
+                s.tokens.append([])
+        # 2. one decode call for every stream that is decoding
+        act = [(sid, s) for sid, s in self.sessions.items() if s.decoding]
+        if not act:
+            return out
+        n = self.group      # every stream keeps its own group boundaries; steps past a stream's token cap are discarded below
+        slots = torch.tensor([s.slot for _, s in act], device=dev, dtype=torch.int32)
+        idx = slots.long()
+        W = max(s.p1 + s.done for _, s in act) + n + 8
+        ids = self.ids[idx, :W].contiguous()
+        ids_len = self.ids_len[idx].contiguous()
+        fin = self.finished[idx].contiguous()
+        B = len(act)
+        toks = torch.full((B, n), self.stop, device=dev, dtype=torch.int32)
+        lats = torch.empty(B, n, m.gpt.model_dim, device=dev, dtype=torch.float32)
+        self.params.seed = self.calls          # a fresh counter-RNG stream per call (only matters for top_k > 1)
+        self.calls += 1
+        eng.generate(slots, ids, ids_len, fin, self.params, 0, n, toks, lats)
+        self.ids[idx, :W] = ids
+        self.ids_len[idx] = ids_len
+        self.finished[idx] = fin
+        th = toks.cpu()
+        keep = []
+        for b, (sid, s) in enumerate(act):
+            hit = (th[b] == self.stop).nonzero()
+            nb = int(hit[0]) + 1 if hit.numel() else n            # the EOS step is part of the group (reference :189-196)
+            nb = min(nb, self.max_new - s.done)                   # max_length cap of the reference loop (gpt.py:606,618)
+            s.done += nb
+            s.tokens[-1].append(toks[b:b + 1, :nb].long())
+            if (hit.numel() and int(hit[0]) < nb) or s.done >= self.max_new:
+                s.decoding = False
+                s.tokens[-1] = torch.cat(s.tokens[-1], 1)
+            keep.append(nb)
+        # 3. vocoder, batched over equal group lengths
+        for nb in sorted(set(keep)):
+            rows = [b for b in range(B) if keep[b] == nb]
+            audio = _vocode(m, lats[rows, :nb].contiguous())
+            if audio is None:
+                continue
+            for j, b in enumerate(rows):
+                sid, s = act[b]
+                chunk, s.prev, s.overlap = handle_chunks(audio[j].squeeze(), s.prev, s.overlap, 1024)
+                out.setdefault(sid, []).append(chunk)
+        return out

@@ -174,3 +174,45 @@ def test_infer_cli_from_checkpoint_file(tmp_path):
     d = synthesize_utt(m1, src, ref, return_details=True)
     assert torch.equal(torch.cat(d["codes"]).cpu(), tok["tokens"][0])
     _m.clear()
+
+
+def test_stream_sessions_scheduler_matches_solo_conversions():
+    """row f4: sessions opened and fed at different times share decode steps (ragged positions, different phases) and
+    each still gets the tokens / waveform of its solo `synthesize_utt_streaming` conversion"""
+    from genvc_amd.inference.inference_utils import segments, synthesize_utt_streaming
+    from genvc_amd.streaming import StreamSessions
+    m = tiny_model(3)
+    m.gpt.max_gen_mel_tokens = 30
+    refs = [synth.synth_audio(60 + i, "ref", 72000) for i in range(3)]
+    srcs = [synth.synth_audio(80 + i, "src", n) for i, n in enumerate((32000, 16000, 40000))]     # 2, 1 and 2.5 segments
+    segs = [list(segments(s, 16000, 5120)) for s in srcs]
+    ss = StreamSessions(m, max_sessions=4, group=8)
+    sids, wavs = [], {}
+    sids.append(ss.open(refs[0]))
+    ss.push(sids[0], segs[0][0])
+    steps = 0
+    while True:
+        for sid, chunks in ss.step().items():
+            wavs.setdefault(sid, []).extend(chunks)
+        steps += 1
+        if steps == 1:                                    # the second stream arrives while the first is mid-segment
+            sids.append(ss.open(refs[1]))
+            ss.push(sids[1], segs[1][0])
+            ss.push(sids[0], segs[0][1])
+        if steps == 3:
+            sids.append(ss.open(refs[2]))
+            for sg in segs[2]:
+                ss.push(sids[2], sg)
+        if steps > 3 and ss.idle():
+            break
+        assert steps < 200
+    for i, sid in enumerate(sids):
+        solo = synthesize_utt_streaming(m, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+        toks = ss.close(sid)
+        solo_t = torch.cat(solo["tokens"], 1)[0].cpu()
+        mine = torch.cat([t for t in toks], 1)[0].cpu()
+        assert torch.equal(mine, solo_t), f"stream {i}: tokens differ"
+        w = torch.cat(wavs[sid], -1)
+        assert w.shape == solo["wav"].shape
+        np.testing.assert_allclose(w.cpu().numpy(), solo["wav"].cpu().numpy(), atol=2e-4)
+    _m.clear()
