@@ -190,12 +190,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # dry-run hooks for a box with fewer GPUs than ranks (tests of the multi-rank code path only): every rank on GPU 0,
+    # gloo instead of RCCL (RCCL refuses two ranks on one device)
+    if os.environ.get("GVC_BENCH_SAME_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        backend = os.environ.get("GVC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     wl = Workload(device, rank, args.streams)
     for u in range(args.warmup):
