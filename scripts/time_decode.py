@@ -18,7 +18,7 @@ codes = synth.integers(1, "k", (B, Tc), 256).to(dev).int()
 slots = torch.arange(B, device=dev, dtype=torch.int32)
 prefix = eng.prefix_embeddings(cond, codes)
 P = prefix.shape[1]
-sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=1), 1026, 1025)
+sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=int(os.environ.get("TOPK", "1"))), 1026, 1025)
 
 def run(n):
     ids = torch.ones(B, P + 1 + n + 8, device=dev, dtype=torch.int32); ids[:, P] = 1024
