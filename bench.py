@@ -190,6 +190,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    from genvc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):       # a checkout without the in-tree build: compile it here (hipcc, gfx950)
+        if rank == 0:
+            from genvc_amd.build import build as build_lib
+            build_lib(verbose=False)
+        else:
+            while not os.path.exists(_lib.LIB_PATH):
+                time.sleep(1.0)
     # dry-run hooks for a box with fewer GPUs than ranks (tests of the multi-rank code path only): every rank on GPU 0,
     # gloo instead of RCCL (RCCL refuses two ranks on one device)
     if os.environ.get("GVC_BENCH_SAME_DEVICE"):
