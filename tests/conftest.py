@@ -12,6 +12,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a checkout without the in-tree build (the .so is git-ignored): compile it once, here or on the GPU box
+    from genvc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        from genvc_amd.build import build
+        build(verbose=False)
 
 
 def golden(name):
