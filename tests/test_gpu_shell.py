@@ -216,3 +216,22 @@ def test_stream_sessions_scheduler_matches_solo_conversions():
         assert w.shape == solo["wav"].shape
         np.testing.assert_allclose(w.cpu().numpy(), solo["wav"].cpu().numpy(), atol=2e-4)
     _m.clear()
+
+
+def test_short_tail_segment_is_zero_padded_like_the_reference():
+    """inference_utils.py:43-50: a last segment shorter than 0.32 s is zero-padded to 5120 samples (15 ContentVec frames,
+    4 content codes); streaming and non-streaming conversions agree on it, prefix caching included"""
+    from genvc_amd.inference.inference_utils import segments, synthesize_utt, synthesize_utt_streaming
+    m = tiny_model(3)
+    m.gpt.max_gen_mel_tokens = 20
+    src = synth.synth_audio(15, "src", 16000 + 3000)
+    segs = list(segments(src, 16000, 5120))
+    assert [s.shape[-1] for s in segs] == [16000, 5120] and float(segs[1][0, 3000:].abs().max()) == 0.0
+    ref = synth.synth_audio(16, "ref", 72000)
+    st = synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+    nst = synthesize_utt(m, src, ref, seg_len=1.0, return_details=True)
+    toks_st = torch.cat(st["tokens"], 1)[0]
+    keep = toks_st != m.gpt.stop_audio_token
+    assert torch.equal(toks_st[keep], torch.cat(nst["codes"]))
+    assert len(st["tokens"]) >= 2 and bool(torch.isfinite(st["wav"]).all())
+    _m.clear()
