@@ -63,23 +63,39 @@ __global__ void k_code_norms(const float* embed, float* ee, int dim, int n_embed
     ee[j] = s;
 }
 
-// one workgroup per row of x [N][dim]; embed [dim][n_embed]; idx[row] = argmax_j -((xx - 2 x.e_j) + ee_j)
-__global__ __launch_bounds__(256) void k_vq_argmin(const float* x, const float* embed, const float* ee, int dim,
-                                                   int n_embed, int32_t* idx) {
-    extern __shared__ float xs[];              // [dim] + reduction scratch
-    __shared__ float rv[4];
-    __shared__ int ri[4];
-    __shared__ float red[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
+// one workgroup (1024 threads) per row of x [N][dim]; embed [dim][n_embed]; idx[row] = argmax_j -((xx - 2 x.e_j) + ee_j).
+// Thread (g, j) accumulates the quarter g of the dot product of code j (coalesced over j); the four quarters are added
+// in LDS, then the reference's expression is evaluated per code and the first index wins ties.
+constexpr int kVqThreads = 1024;
+__global__ __launch_bounds__(kVqThreads) void k_vq_argmin(const float* x, const float* embed, const float* ee, int dim,
+                                                          int n_embed, int32_t* idx) {
+    extern __shared__ float xs[];              // [dim] + [4][n_embed] partial dots
+    __shared__ float rv[kVqThreads / 64];
+    __shared__ int ri[kVqThreads / 64];
+    __shared__ float red[kVqThreads / 64];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pd = xs + dim;
     const float* xr = x + (size_t)row * dim;
     float q = 0.f;
-    for (int i = tid; i < dim; i += 256) { const float v = xr[i]; xs[i] = v; q += v * v; }
-    const float xx = block4_sum(q, red);        // also orders the xs[] writes before the reads below
+    for (int i = tid; i < dim; i += kVqThreads) { const float v = xr[i]; xs[i] = v; q += v * v; }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    float xx = 0.f;
+#pragma unroll
+    for (int w = 0; w < kVqThreads / 64; ++w) xx += red[w];
+    const int g = tid >> 8, jj = tid & 255;
+    const int i0 = g * (dim / 4), i1 = g == 3 ? dim : (g + 1) * (dim / 4);
+    for (int j = jj; j < n_embed; j += 256) {
+        float dot = 0.f;
+        for (int i = i0; i < i1; ++i) dot = fmaf(xs[i], embed[(size_t)i * n_embed + j], dot);
+        pd[g * n_embed + j] = dot;
+    }
+    __syncthreads();
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int j = tid; j < n_embed; j += 256) {
-        float dot = 0.f;
-        for (int i = 0; i < dim; ++i) dot = fmaf(xs[i], embed[(size_t)i * n_embed + j], dot);
+    for (int j = tid; j < n_embed; j += kVqThreads) {
+        const float dot = (pd[j] + pd[n_embed + j]) + (pd[2 * n_embed + j] + pd[3 * n_embed + j]);
         const float dist = (xx - 2.0f * dot) + ee[j];
         const float sc = -dist;
         if (sc > best || (sc == best && j < bi)) { best = sc; bi = j; }
@@ -89,10 +105,10 @@ __global__ __launch_bounds__(256) void k_vq_argmin(const float* x, const float* 
         const int oi = __shfl_xor(bi, off);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
-    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < kVqThreads / 64; ++w)
             if (rv[w] > best || (rv[w] == best && ri[w] < bi)) { best = rv[w]; bi = ri[w]; }
         idx[row] = bi;
     }
@@ -316,7 +332,7 @@ static int dvae_run(gvc_dvae* c, int B, int T, int32_t* codes_out, float* enc_ou
     float* enc = enc_out ? enc_out : c->enc;
     if ((rc = conv_gemm(c, c->last, cur, Tc, 1, enc, Tc, B, ACT_NONE, nullptr, false, s))) return rc;
     const int dim = c->dm.codebook_dim;
-    hipLaunchKernelGGL(k_vq_argmin, dim3(B * Tc), dim3(256), dim * sizeof(float), s, enc, c->embed, c->ee, dim,
+    hipLaunchKernelGGL(k_vq_argmin, dim3(B * Tc), dim3(kVqThreads), (dim + 4 * c->dm.num_tokens) * sizeof(float), s, enc, c->embed, c->ee, dim,
                        c->dm.num_tokens, codes_out);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
@@ -328,7 +344,7 @@ extern "C" int gvc_vq_argmin(const float* x, const float* embed, int32_t N, int3
     hipStream_t s = (hipStream_t)sv;
     hipLaunchKernelGGL(k_code_norms, dim3(cdiv(n_embed, 256)), dim3(256), 0, s, embed, work, dim, n_embed);
     GVC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_vq_argmin, dim3(N), dim3(256), dim * sizeof(float), s, x, embed, work, dim, n_embed, idx);
+    hipLaunchKernelGGL(k_vq_argmin, dim3(N), dim3(kVqThreads), (dim + 4 * n_embed) * sizeof(float), s, x, embed, work, dim, n_embed, idx);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
