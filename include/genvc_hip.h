@@ -94,7 +94,9 @@ int gvc_gpt_prefill(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* 
 /* Prefix caching: the same call when the first n_cached rows of prefix_emb (the 32 conditioning latents of the reference
  * speaker, identical for every segment of an utterance: inference_utils.py:43-66 rebuilds them per segment) are ALREADY in
  * the slots' KV cache from an earlier gvc_gpt_prefill[_cached] with the same leading rows.  Only rows n_cached..P are
- * computed and appended; results are bit-identical to the full prefill.  The caller vouches for the cache contents. */
+ * computed and appended; results are bit-identical to the full prefill while the uncached rows fit the skinny path (<= 128
+ * rows per call) and equal to rounding on the tiled path (its split-K depends on the row count).  The caller vouches for
+ * the cache contents. */
 int gvc_gpt_prefill_cached(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
                            int32_t n_cached, int32_t start_tok, float* logits_out, float* latent_out, gvc_stream s);
 

@@ -390,3 +390,29 @@ def test_prefix_cache_prefill_is_bit_identical(margs):
     from genvc_amd._lib import GenvcHipError
     with pytest.raises(GenvcHipError):
         eng.prefill(s_cached, pb, n_cached=pb.shape[1] + 1)
+
+
+def test_prefix_cache_with_a_long_segment_uses_the_tiled_path():
+    """more than 128 uncached rows: the cached prefill runs on the tiled GEMM with the per-slot base offset; split-K depends
+    on the row count there, so it matches the full prefill to rounding (not bit for bit) and the oracle within 1e-4"""
+    from oracle import genvc_oracle as O
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3)
+    wc = cpu_weights(w)
+    dev = "cuda"
+    cond = synth.uniform(93, "cond_latents", (1, 32, dims["d_model"]), 1.0)
+    codes_a = synth.integers(93, "codes_a", (1, 40), 256)
+    codes_b = synth.integers(94, "codes_b", (1, 300), 256)                      # 302 + 1 uncached rows
+    s0 = torch.zeros(1, device=dev, dtype=torch.int32)
+    s1 = torch.ones(1, device=dev, dtype=torch.int32)
+    eng.prefill(s0, eng.prefix_embeddings(cond.to(dev), codes_a.to(dev).int()), want_outputs=False)
+    pb = eng.prefix_embeddings(cond.to(dev), codes_b.to(dev).int())
+    lg_c, lat_c = eng.prefill(s0, pb, n_cached=32)
+    lg_f, lat_f = eng.prefill(s1, pb)
+    np.testing.assert_allclose(lg_c.cpu().numpy(), lg_f.cpu().numpy(), atol=2e-5)
+    pe, _ = O.compute_embeddings(wc, dims, cond, codes_b)
+    z, logits, cache = O.gpt_prefill(wc, dims, pe)
+    np.testing.assert_allclose(lg_c.cpu().numpy(), logits.numpy(), atol=1e-4)
+    tok = torch.tensor([7], device=dev, dtype=torch.int32)
+    a, _ = eng.decode_step(s0, tok)
+    _, ref, _ = O.gpt_decode_step(wc, dims, cache, torch.tensor([7]), 1)
+    np.testing.assert_allclose(a.cpu().numpy(), ref.numpy(), atol=1e-4)
