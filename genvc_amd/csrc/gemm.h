@@ -92,10 +92,19 @@ __global__ void k_splitk_epilogue(const GemmArgs G);
 // G.SK > 1: the K range is also split over blockIdx.y and RAW partial sums go to G.work[sk][M][N] (the consumer,
 // k_ln_sum_rows, adds them together with bias and residual: no separate split-K epilogue launch).
 int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s);
-// x[row] += bias + sum_s part[s][row];  a[row] = LayerNorm(x[row]) (skipped when ln_w is null); one workgroup per
-// row (grid = rows, 256 threads), d <= 4096, SK <= 8
-__global__ void k_ln_sum_rows(float* x, float* a, const float* part, int SK, const float* bias, int rows, int d,
-                              const float* ln_w, const float* ln_b, int a_fm16);
+// x_out[row] = x_in[row] + bias + sum_s part[s][row];  a[row] = LayerNorm(x_out[row]) (skipped when ln_w is null); one wave per
+// row, d = 256 or 1024, SK <= 8; x_out may be x_in
+int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* part, int SK, const float* bias, int rows, int d,
+                       const float* ln_w, const float* ln_b, int a_fm16, hipStream_t s);
+// the same row completion + LayerNorm folded into the prologue of the skinny GEMM (<= 16 rows, K = d): see gemm.hip
+struct LnFuse {
+    const float* x_in; float* x_out;       // [rows][d]; x_out null: nothing to complete (part == null), keep x_in
+    const float* part; int SK; const float* pbias;
+    const float* ln_w; const float* ln_b;
+    int rows;
+};
+int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s);
+void gemm_init_attributes();        // raises dynamic-LDS limits; call once, outside stream capture
 // row-major [N][K] -> FM16
 __global__ void k_to_fm16(const float* src, float* dst, int N, int K);
 

@@ -211,61 +211,182 @@ __global__ void k_to_fm16(const float* src, float* dst, int N, int K) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ln_sum_rows(float* x, float* a, const float* part, int SK, const float* bias,
-                                                     int rows, int d, const float* ln_w, const float* ln_b, int a_fm16) {
-    __shared__ float red[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    float* xr = x + (size_t)row * d;
-    const size_t pstride = (size_t)rows * d;
-    constexpr int MAXV = 4;                          // d <= 4096
-    float4 v[MAXV];
+// ---- row completion + LayerNorm, ONE WAVE PER ROW (the order every path shares, fused or not) ----
+// lane L owns the float4s at k = (i*64 + L)*4, i < NV (d = 256*NV).  v = x + bias + part[0] + ... + part[SK-1] (in that
+// order); mean and variance by a per-lane sum over i followed by wave_sum.
+template <int NV>
+__device__ __forceinline__ void row_sum(const float* xr, const float* part, size_t prow, size_t pstride, int SK, const float* bias,
+                                        int lane, float4 (&v)[NV]) {
+    // SK is 4 on every caller's path (wave-uniform branch); the general case loops
+    float4 b4[NV], p4[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        v[i] = *reinterpret_cast<const float4*>(xr + k);
+        if (part) {
+            b4[i] = *reinterpret_cast<const float4*>(bias + k);
+            if (SK == 4) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) p4[i][sidx] = *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k);
+            }
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x += b4[i].x; v[i].y += b4[i].y; v[i].z += b4[i].z; v[i].w += b4[i].w;
+            if (SK == 4) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) { v[i].x += p4[i][sidx].x; v[i].y += p4[i][sidx].y; v[i].z += p4[i][sidx].z; v[i].w += p4[i][sidx].w; }
+            } else {
+                const int k = (i * 64 + lane) * 4;
+                for (int sidx = 0; sidx < SK; ++sidx) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k);
+                    v[i].x += q4.x; v[i].y += q4.y; v[i].z += q4.z; v[i].w += q4.w;
+                }
+            }
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void row_ln(const float4 (&v)[NV], const float* ln_w, const float* ln_b, int lane, float4 (&o)[NV]) {
+    constexpr float inv_d = 1.0f / (float)(256 * NV);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int k = (i * 256 + tid) * 4;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < d) {
-            v[i] = *reinterpret_cast<const float4*>(xr + k);
-            const float4 b4 = *reinterpret_cast<const float4*>(bias + k);
-            float4 p4[8];
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
 #pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx)
-                p4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + sidx * pstride + (size_t)row * d + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-            v[i].x += b4.x; v[i].y += b4.y; v[i].z += b4.z; v[i].w += b4.w;
-#pragma unroll
-            for (int sidx = 0; sidx < 8; ++sidx) { v[i].x += p4[sidx].x; v[i].y += p4[sidx].y; v[i].z += p4[sidx].z; v[i].w += p4[sidx].w; }
-            *reinterpret_cast<float4*>(xr + k) = v[i];
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
+    for (int i = 0; i < NV; ++i) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        const float4 gw = *reinterpret_cast<const float4*>(ln_w + k);
+        const float4 gb = *reinterpret_cast<const float4*>(ln_b + k);
+        o[i].x = (v[i].x - mean) * rstd * gw.x + gb.x; o[i].y = (v[i].y - mean) * rstd * gw.y + gb.y;
+        o[i].z = (v[i].z - mean) * rstd * gw.z + gb.z; o[i].w = (v[i].w - mean) * rstd * gw.w + gb.w;
+    }
+}
+
+// x_out[row] = x_in[row] + bias + sum_s part[s][row];  a[row] = LayerNorm(x_out[row]) (skipped when ln_w is null).
+// grid = rows, 64 threads: one wave per row.  x_out may be x_in.
+template <int NV>
+__global__ __launch_bounds__(64) void k_ln_sum_rows_t(const float* x_in, float* x_out, float* a, const float* part, int SK,
+                                                       const float* bias, int rows, const float* ln_w, const float* ln_b, int a_fm16) {
+    constexpr int d = 256 * NV;
+    const int lane = threadIdx.x, row = blockIdx.x;
+    float4 v[NV], o[NV];
+    row_sum<NV>(x_in + (size_t)row * d, part, (size_t)row * d, (size_t)rows * d, SK, bias, lane, v);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(x_out + (size_t)row * d + (i * 64 + lane) * 4) = v[i];
     if (!ln_w) return;
-    const float inv_d = 1.0f / (float)d;
-    const float mean = block4_sum(s, red) * inv_d;
-    float qv = 0.f;
+    row_ln<NV>(v, ln_w, ln_b, lane, o);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int k = (i * 256 + tid) * 4;
-        if (k < d) {
-            const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-            qv += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    for (int i = 0; i < NV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        if (a_fm16) *reinterpret_cast<float4*>(a + fm16_index(row, k, d)) = o[i];
+        else *reinterpret_cast<float4*>(a + (size_t)row * d + k) = o[i];
+    }
+}
+
+int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* part, int SK, const float* bias, int rows, int d,
+                       const float* ln_w, const float* ln_b, int a_fm16, hipStream_t s) {
+    GVC_REQUIRE((d == 1024 || d == 256) && SK >= 0 && SK <= 8, GVC_ERR_UNSUPPORTED, "ln_sum_rows: d=%d SK=%d unsupported", d, SK);
+    if (d == 1024) hipLaunchKernelGGL(k_ln_sum_rows_t<4>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
+    else hipLaunchKernelGGL(k_ln_sum_rows_t<1>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+// ---- skinny GEMM for <= 16 rows with the row completion + LayerNorm in its prologue (K = d) ----
+// A = LayerNorm(x_in + bias + sum part) is built by the workgroup itself (wave w: rows w and w + 8) and staged in LDS in
+// the FM16 fragment order; workgroup 0 also writes the completed rows to x_out (a buffer other than x_in: the other
+// workgroups are still reading x_in).  Everything else as k_gemm_skinny<1, 8>: same per-element summation order, so the
+// result is bit-identical to k_ln_sum_rows_t followed by k_gemm_skinny.
+
+template <int NV>
+__global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const LnFuse P) {
+    constexpr int K = 256 * NV, K16 = K / 16, NW = 8, kw = K / NW;           // kw = 128 (d = 1024) or 32 (d = 256)
+    constexpr int U = kw / 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* a_lds = sm;                                 // one 16-row M tile in FM16 order: [K16][256]
+    float (*red)[256] = reinterpret_cast<float (*)[256]>(sm + 16 * K);       // [NW][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    float4 w4[U];
+    const float* wp = G.Wt + ((size_t)(n0 >> 4) * K16 + (wave * kw >> 4)) * 256 + lane * 4;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = wave + 8 * rr;
+        float4 o[NV];
+        if (row < P.rows) {
+            float4 v[NV];
+            row_sum<NV>(P.x_in + (size_t)row * K, P.part, (size_t)row * K, (size_t)P.rows * K, P.SK, P.pbias, lane, v);
+            if (rr == 1) {          // the weight fragments are requested once the prologue's own operands are on their way
+#pragma unroll
+                for (int u = 0; u < U; ++u) w4[u] = *reinterpret_cast<const float4*>(wp + u * 256);
+            }
+            if (P.x_out && blockIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(P.x_out + (size_t)row * K + (i * 64 + lane) * 4) = v[i];
+            }
+            row_ln<NV>(v, P.ln_w, P.ln_b, lane, o);
+        } else {
+            if (rr == 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) w4[u] = *reinterpret_cast<const float4*>(wp + u * 256);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = (i * 64 + lane) * 4;
+            *reinterpret_cast<float4*>(a_lds + (size_t)(k >> 4) * 256 + (((row & 15) + 16 * ((k & 15) >> 2)) << 2)) = o[i];
         }
     }
-    const float rstd = 1.0f / sqrtf(block4_sum(qv, red) * inv_d + 1e-5f);
-    float* ar = a + (size_t)row * d;
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = a_lds + (size_t)(wave * kw >> 4) * 256 + lane * 4;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int k = (i * 256 + tid) * 4;
-        if (k < d) {
-            const float4 gw = *reinterpret_cast<const float4*>(ln_w + k);
-            const float4 gb = *reinterpret_cast<const float4*>(ln_b + k);
-            float4 o;
-            o.x = (v[i].x - mean) * rstd * gw.x + gb.x; o.y = (v[i].y - mean) * rstd * gw.y + gb.y;
-            o.z = (v[i].z - mean) * rstd * gw.z + gb.z; o.w = (v[i].w - mean) * rstd * gw.w + gb.w;
-            if (a_fm16) *reinterpret_cast<float4*>(a + fm16_index(row, k, d)) = o;
-            else *reinterpret_cast<float4*>(ar + k) = o;
-        }
+    for (int u = 0; u < U; ++u) {
+        const float4 a4 = *reinterpret_cast<const float4*>(ap + u * 256);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4[u].w, acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][q * 64 + lane] = acc[q];
+    __syncthreads();
+    if (tid < 256) {
+        const int q = tid >> 6;
+        const int m = 4 * (lane >> 4) + q, n = n0 + (lane & 15);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][q * 64 + lane];
+        if (m < G.M) gemm_store(G, 0, m, n, v);
+    }
+}
+
+int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
+    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && (G.K == 1024 || G.K == 256), GVC_ERR_ARG,
+                "skinny gemm + LN: unsupported shape M=%d N=%d K=%d", G.M, G.N, G.K);
+    G.SK = 1;
+    const size_t lds = ((size_t)16 * G.K + 8 * 256) * sizeof(float);
+    if (G.K == 1024) hipLaunchKernelGGL(k_gemm_skinny_ln<4>, dim3(G.N / 16), dim3(512), lds, s, G, P);
+    else hipLaunchKernelGGL(k_gemm_skinny_ln<1>, dim3(G.N / 16), dim3(512), lds, s, G, P);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
+void gemm_init_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 }
 
 int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {

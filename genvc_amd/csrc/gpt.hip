@@ -217,6 +217,8 @@ struct gvc_gpt {
     int* seam_err_host = nullptr;                 // pinned, device-visible: set when an in-kernel exchange timed out
     int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
+    int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
+    float* xalt = nullptr;                        // second residual buffer of that path [16][d]
     int rows_decode_min = 7;                      // batches of at least this many streams decode on the MFMA rows path (0: never)
     float *logits = nullptr, *latent = nullptr;             // staging of the generation loop, indexed by position in the call
     float *slot_logits = nullptr, *slot_latent = nullptr;   // ... parked per slot between calls   // generate(): [slots][V], [slots][d]
@@ -289,6 +291,9 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     }
     c->n_expected = 10 + 12 * (int)L;
     if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
+    if (getenv("GVC_FUSE_LN")) c->fuse_ln = atoi(getenv("GVC_FUSE_LN"));
+    gemm_init_attributes();
+    GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
     if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
     c->bf16 = D.weight_dtype == 1;
     GVC_REQUIRE(D.weight_dtype == 0 || D.weight_dtype == 1, GVC_ERR_ARG, "weight_dtype must be 0 (fp32) or 1 (bf16)");
@@ -364,6 +369,7 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->sched) hipFree(c->sched);
     if (c->prog) hipFree(c->prog);
     if (c->seam_gran) hipFree(c->seam_gran);
+    if (c->xalt) hipFree(c->xalt);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->slot_logits, (void*)c->slot_latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
@@ -782,8 +788,55 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
                            (const float*)nullptr, skinny ? 1 : 0);
     };
     auto ln_sum = [&](const float* part, const float* bias, const float* w, const float* b) {
-        hipLaunchKernelGGL(k_ln_sum_rows, dim3(rows), dim3(256), 0, s, c->x, c->a, part, SKP, bias, rows, d, w, b, 1);
+        (void)launch_ln_sum_rows(c->x, c->x, c->a, part, SKP, bias, rows, d, w, b, 1, s);
     };
+    // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
+    // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
+    // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
+    if (skinny && rows <= 16 && c->fuse_ln) {
+        float* X[2] = {c->x, c->xalt};
+        int cur = 0;
+        for (int l = 0; l < c->dm.n_layer; ++l) {
+            const GptLayer& ly = c->layers[l];
+            GemmArgs G;
+            LnFuse P;
+            memset(&G, 0, sizeof(G));
+            memset(&P, 0, sizeof(P));
+            P.x_in = X[cur]; P.ln_w = ly.ln1_w; P.ln_b = ly.ln1_b; P.rows = rows;
+            if (l > 0) { P.part = part_p2; P.SK = SKP; P.pbias = c->layers[l - 1].p2_b; P.x_out = X[cur ^ 1]; }
+            G.Wt = ly.qkv_f; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+            G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
+            G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
+            G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
+            G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+            if ((rc = launch_gemm_skinny_ln(G, P, s))) return rc;
+            if (l > 0) cur ^= 1;
+
+            AttnArgs At = gpt_attn_args(c, l, slots);
+            At.q = c->q; At.T = T; At.base_len = base_len;
+            At.out = c->a; At.out_stride = d; At.out_fm16 = 1;
+            if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
+
+            memset(&G, 0, sizeof(G));
+            G.A = c->a; G.lda = d; G.Wt = ly.proj_f; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d; G.work = part_proj;
+            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
+
+            memset(&G, 0, sizeof(G));
+            memset(&P, 0, sizeof(P));
+            P.x_in = X[cur]; P.x_out = X[cur ^ 1]; P.part = part_proj; P.SK = SKP; P.pbias = ly.proj_b;
+            P.ln_w = ly.ln2_w; P.ln_b = ly.ln2_b; P.rows = rows;
+            G.Wt = ly.fc_f; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+            G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = 1;
+            if ((rc = launch_gemm_skinny_ln(G, P, s))) return rc;
+            cur ^= 1;
+
+            memset(&G, 0, sizeof(G));
+            G.A = c->h; G.lda = 4 * d; G.Wt = ly.p2_f; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d; G.work = part_p2;
+            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
+        }
+        // fold the last layer's mlp partials into the residual stream, landing in c->x (what the head reads)
+        return launch_ln_sum_rows(X[cur], c->x, c->a, part_p2, SKP, c->layers[c->dm.n_layer - 1].p2_b, rows, d, nullptr, nullptr, 1, s);
+    }
     for (int l = 0; l < c->dm.n_layer; ++l) {
         const GptLayer& ly = c->layers[l];
         if (skinny && l > 0) ln_sum(part_p2, c->layers[l - 1].p2_b, ly.ln1_w, ly.ln1_b);
