@@ -17,7 +17,7 @@ N > 1: one process per GPU, utterances sharded by rank, no collective on the dat
 token ids are all-gathered (RCCL) inside the timed region.  value = utterances/s of the whole job.
 
 `--streams B` (default 1 = the headline configuration) steps B concurrent streams per GPU together (BASELINE
-configs[3] shape: shared launches, one decode step for all streams; the MFMA rows path from 7 streams up); a step is
+configs[3] shape: shared launches, one decode step for all streams; the MFMA rows path from 5 streams up); a step is
 then B utterances and the JSON line says so in `config.workload`.
 """
 import argparse

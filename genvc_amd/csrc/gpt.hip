@@ -219,7 +219,8 @@ struct gvc_gpt {
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
     float* xalt = nullptr;                        // second residual buffer of that path [16][d]
-    int rows_decode_min = 7;                      // batches of at least this many streams decode on the MFMA rows path (0: never)
+    int rows_decode_min = 5;                      // batches of at least this many streams decode on the MFMA rows path (0: never);
+                                                  // measured crossover: B=4 925 (GEMV) vs 975 us (rows), B=5 1242 vs 996 us
     float *logits = nullptr, *latent = nullptr;             // staging of the generation loop, indexed by position in the call
     float *slot_logits = nullptr, *slot_latent = nullptr;   // ... parked per slot between calls   // generate(): [slots][V], [slots][d]
     int32_t* state = nullptr;         // seq_len[slots], mel_pos[slots], tok[slots], step

@@ -143,7 +143,7 @@ def synthesize_streams_streaming(genVC_mdl, src_wavs, tgt_audios, seg_len=1.0, s
     """BASELINE configs[3]: B concurrent streams stepped together.  Each stream is converted exactly as
     `synthesize_utt_streaming` converts it on its own (same segments, same per-stream EOS rule, same vocoder grouping and
     cross-fade); the streams only SHARE the launches: ContentVec / DVAE / prefill / vocoder run on the batch and one
-    decode step serves every stream (the MFMA rows path from 7 streams up).
+    decode step serves every stream (the MFMA rows path from 5 streams up).
 
     src_wavs [B,T] (equal lengths), tgt_audios [B,Tr] or [1,Tr] (one reference for all).
     Returns per-stream lists: wav [B] tensors, tokens, plus first-chunk latency and the batch RTF."""

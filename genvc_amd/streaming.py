@@ -8,7 +8,7 @@ per open stream and, at every `step()`, batches whatever the open streams need n
     batched over the streams whose segment has the same length (the conditioning rows of a stream stay in its slot after
     its first segment: `gvc_gpt_prefill_cached`);
   * streams that are decoding: ONE `gvc_gpt_generate` call of `group` steps over all of them, whatever their positions
-    (per-slot cache lengths live on the device; the MFMA rows path from 7 streams up);
+    (per-slot cache lengths live on the device; the MFMA rows path from 5 streams up);
   * the vocoder for the token groups that came out, batched over equal group lengths, cross-faded per stream exactly as
     `handle_chunks` does inside `synthesize_utt_streaming`.
 

@@ -196,10 +196,14 @@ def test_missing_weights_fail_loudly():
         eng.decode_step(slots, slots)
 
 
-def test_batch5_and_long_context_teacher_forced_vs_oracle():
-    """edge cases: a batch that pads to the 8-stream kernel, mel positions up to the 602 cap, a context long
-    enough for the split-key (unfused) attention path; logits teacher-forced against the oracle."""
+@pytest.mark.parametrize("rows_min", ["0", "5"], ids=["gemv8", "rows"])
+def test_batch5_and_long_context_teacher_forced_vs_oracle(rows_min, monkeypatch):
+    """edge cases: a batch of 5 on the padded 8-stream GEMV kernels (GVC_ROWS_DECODE_MIN=0) and on the MFMA rows path
+    (the default from 5 streams up), mel positions up to the 602 cap, a context long enough for the split-key
+    (unfused) attention path; logits teacher-forced against the oracle."""
     from oracle import genvc_oracle as O
+    monkeypatch.setenv("GVC_ROWS_DECODE_MIN", rows_min)
+    _cache.clear()
     dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3)
     wc = cpu_weights(w)
     dev = "cuda"
@@ -221,6 +225,7 @@ def test_batch5_and_long_context_teacher_forced_vs_oracle():
         if j in check_at:
             np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=2e-4)
             np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=2e-4)
+    _cache.clear()                                      # the engine was created under this test's GVC_ROWS_DECODE_MIN
 
 
 def test_maximum_prefix_uses_the_tiled_gemm_path():
@@ -305,7 +310,7 @@ def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n
 
 @pytest.mark.parametrize("B", [8, 16, 19])
 def test_rows_mode_batched_decode_vs_oracle(B):
-    """B >= 7 streams decode on the MFMA rows path (one pass over the weights for up to 128 streams): ragged cache
+    """B >= 5 streams decode on the MFMA rows path (one pass over the weights for up to 128 streams): ragged cache
     lengths, teacher-forced logits/latents against the oracle, and the K/V rows it appends feed later steps."""
     from oracle import genvc_oracle as O
     dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, 3, max_slots=24)

@@ -105,7 +105,7 @@ def test_harness_streaming_and_offline_agree():
 
 @pytest.mark.parametrize("B", [3, 8])
 def test_concurrent_streams_equal_single_stream_conversions(B):
-    """BASELINE configs[3]: B streams stepped together (shared launches; rows-path decode from 7 streams up) give each
+    """BASELINE configs[3]: B streams stepped together (shared launches; rows-path decode from 5 streams up) give each
     stream the tokens and waveform it gets when converted alone."""
     from genvc_amd.inference.inference_utils import synthesize_streams_streaming, synthesize_utt_streaming
     m = tiny_model(3)
