@@ -153,3 +153,18 @@ def test_hubert_rejects_short_and_oversized_input():
         eng.forward(torch.zeros(1, 16001, device=DEV))
     with pytest.raises(GenvcHipError):
         eng.forward(torch.zeros(2, 8000, device=DEV))
+
+
+def test_hubert_batches_agree_with_single_items():
+    """batch invariance across the transformer paths: 2 x 49 frames (skinny, 7 M-tiles), 3 x 49 (tiled), 1 x 49 (skinny, 4)"""
+    from genvc_amd.engine import HubertEngine
+    c = gcfg.DEFAULT_HUBERT
+    eng = HubertEngine(c, max_batch=3, max_samples=16000)
+    eng.bind(synth.make_weights(17, synth.hubert_weight_spec(c), device=DEV))
+    wav = torch.cat([synth.synth_audio(30 + b, "w", 16000) for b in range(3)], 0).to(DEV)
+    solo = [eng.forward(wav[b:b + 1].contiguous()) for b in range(3)]
+    for B in (2, 3):
+        got = eng.forward(wav[:B].contiguous())
+        for b in range(B):
+            np.testing.assert_allclose(got[b].cpu().numpy(), solo[b][0].cpu().numpy(), atol=2e-5)
+    eng.close()
