@@ -110,7 +110,7 @@ __global__ void k_conv_post_tanh(const float* x, const float* w, const float* bi
 }
 
 // ---------------------------------------------------------------------------------------------
-// ResBlock conv of the last two stages (C = 32 or 64 channels in and out, k <= 7 taps, dilation <= 12): the whole
+// ResBlock convs (C = 32, 64 or 128 channels in and out, k <= 7 taps, dilation <= 12): the whole
 // K = k*C extent is small, so instead of the tiled GEMM's k-loop (one global->LDS->sync round trip per 32 columns:
 // 11-22 us for 0.1 GFLOP) a workgroup stages EVERYTHING it needs in one round trip -- the 32 + (k-1)*dil input rows of
 // its 32 output frames (leaky-ReLU applied while staging) and the full [C][k*C] weight matrix -- and then runs the
@@ -123,6 +123,7 @@ struct ConvSmallArgs {
     const float* w; const float* b;      // [C][k*C] (column tap*C + ci), [C]
     const float* resid; const float* resid2;
     int T, k, dil;
+    int tap_chunk;                       // taps of the weight tile staged in LDS at a time
     float slope, out_scale;
 };
 
@@ -133,10 +134,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
     // grid (T/32, C/32, B): a workgroup owns 32 frames x one 32-channel tile of the outputs; NW waves split the reduction
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int XS = C + 4, NTH = NW * 64;
-    const int K = A.k * C, WS = K + 4;
+    const int K = A.k * C;
+    const int tc = A.tap_chunk;                 // taps of W staged at a time (all of them when the tile fits in LDS)
+    const int WS = tc * C + 4;
     const int R = 32 + (A.k - 1) * A.dil;
     float* Xs = lds;                       // [R][XS]
-    float* Ws = lds + (size_t)R * XS;      // [32][WS]
+    float* Ws = lds + (size_t)R * XS;      // [32][WS]: taps [tap0, tap0 + tc) of the 32-channel weight tile
     float* red = lds;                      // [NW][16][64] after the MFMA loop (aliases Xs/Ws)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, b = blockIdx.z;
@@ -150,24 +153,28 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
         v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
         *reinterpret_cast<float4*>(&Xs[r * XS + c4]) = v;
     }
-    for (int i = tid; i < 32 * (K / 4); i += NTH) {
-        const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
-        *reinterpret_cast<float4*>(&Ws[n * WS + k4]) = *reinterpret_cast<const float4*>(A.w + (size_t)(n0 + n) * K + k4);
-    }
-    __syncthreads();
     hf_f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int m = lane & 31, half = lane >> 5;
-    const int steps = A.k * (C / 8);
-    for (int it = wave; it < steps; it += NW) {
-        const int tap = it / (C / 8), q = it - tap * (C / 8);
-        const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(m + tap * A.dil) * XS + 8 * q + 4 * half]);
-        const float4 b4 = *reinterpret_cast<const float4*>(&Ws[m * WS + tap * C + 8 * q + 4 * half]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    for (int tap0 = 0; tap0 < A.k; tap0 += tc) {
+        const int nt = min(tc, A.k - tap0), kc4 = nt * C / 4;
+        if (tap0 > 0) __syncthreads();             // the previous chunk of W has been consumed
+        for (int i = tid; i < 32 * kc4; i += NTH) {
+            const int n = i / kc4, k4 = (i % kc4) * 4;
+            *reinterpret_cast<float4*>(&Ws[n * WS + k4]) = *reinterpret_cast<const float4*>(A.w + (size_t)(n0 + n) * K + tap0 * C + k4);
+        }
+        __syncthreads();
+        const int steps = nt * (C / 8);
+        for (int it = wave; it < steps; it += NW) {
+            const int tl = it / (C / 8), q = it - tl * (C / 8);
+            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(m + (tap0 + tl) * A.dil) * XS + 8 * q + 4 * half]);
+            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[m * WS + tl * C + 8 * q + 4 * half]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
     }
     __syncthreads();                      // everyone is done reading Xs / Ws: the region becomes the reduction buffer
 #pragma unroll
@@ -288,6 +295,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     // up to ~150 KB of dynamic LDS (64 channels, 7 taps): raise the per-kernel limit once, outside any capture
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     *out = c;
     return GVC_OK;
@@ -361,24 +369,29 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
 extern "C" int gvc_hifigan_missing_weights(gvc_hifigan* c) { return c ? c->n_expected - (int)c->bound.size() : -1; }
 
 // out rows [PAD, PAD+T) = epilogue(conv(lrelu?(src)))
-static size_t conv_small_lds(const HfConv& w) {
-    const size_t R = 32 + (size_t)(w.k - 1) * w.dil, K = (size_t)w.k * w.Ci;
-    const size_t stage = R * (w.Ci + 4) + (size_t)32 * (K + 4), red = (size_t)8 * 16 * 64;
+// LDS bytes of k_conv_small with `tc` taps of the weight tile resident
+static size_t conv_small_lds(const HfConv& w, int tc) {
+    const size_t R = 32 + (size_t)(w.k - 1) * w.dil;
+    const size_t stage = R * (w.Ci + 4) + (size_t)32 * ((size_t)tc * w.Ci + 4), red = (size_t)8 * 16 * 64;
     return (stage > red ? stage : red) * sizeof(float);
 }
 
 static int hf_conv(gvc_hifigan* c, const HfConv& w, const float* src, float* dst, int T, int B, float a_slope,
                    const float* resid, const float* resid2, float out_scale, hipStream_t s) {
-    if (c->small_conv && w.Ci == w.Co && (w.Ci == 32 || w.Ci == 64) && T % 32 == 0 && a_slope != 0.f &&
-        conv_small_lds(w) <= 160 * 1024) {
-        ConvSmallArgs A;
-        A.x = src; A.y = dst; A.w = w.w; A.b = w.b; A.resid = resid; A.resid2 = resid2; A.T = T; A.k = w.k; A.dil = w.dil;
-        A.slope = a_slope; A.out_scale = out_scale;
-        const size_t lds = conv_small_lds(w);
-        if (w.Ci == 32) hipLaunchKernelGGL((k_conv_small<32, 4>), dim3(T / 32, 1, B), dim3(256), lds, s, A);
-        else hipLaunchKernelGGL((k_conv_small<64, 8>), dim3(T / 32, 2, B), dim3(512), lds, s, A);
-        GVC_LAUNCH_CHECK();
-        return GVC_OK;
+    if (c->small_conv && w.Ci == w.Co && (w.Ci == 32 || w.Ci == 64 || w.Ci == 128) && T % 32 == 0 && a_slope != 0.f) {
+        int tc = w.k;                                    // as many taps of W at a time as fit beside the input rows
+        while (tc > 1 && conv_small_lds(w, tc) > 150 * 1024) --tc;
+        if (conv_small_lds(w, tc) <= 150 * 1024) {
+            ConvSmallArgs A;
+            A.x = src; A.y = dst; A.w = w.w; A.b = w.b; A.resid = resid; A.resid2 = resid2; A.T = T; A.k = w.k; A.dil = w.dil;
+            A.tap_chunk = tc; A.slope = a_slope; A.out_scale = out_scale;
+            const size_t lds = conv_small_lds(w, tc);
+            if (w.Ci == 32) hipLaunchKernelGGL((k_conv_small<32, 4>), dim3(T / 32, 1, B), dim3(256), lds, s, A);
+            else if (w.Ci == 64) hipLaunchKernelGGL((k_conv_small<64, 8>), dim3(T / 32, 2, B), dim3(512), lds, s, A);
+            else hipLaunchKernelGGL((k_conv_small<128, 8>), dim3(T / 32, 4, B), dim3(512), lds, s, A);
+            GVC_LAUNCH_CHECK();
+            return GVC_OK;
+        }
     }
     GemmArgs G;
     memset(&G, 0, sizeof(G));
