@@ -930,11 +930,10 @@ extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t 
     }
     hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, T, 1);
     GVC_LAUNCH_CHECK();
-    if (logits_out == c->logits && latent_out == c->latent) {       // generation staging: park it per slot
-        hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
-        hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, d, 1);
-        GVC_LAUNCH_CHECK();
-    }
+    // park the next-step logits / latent per slot: gvc_gpt_generate continues every slot from here, whoever received them
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, logits_out, c->slot_logits, slots, c->dm.vocab, 1);
+    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, latent_out, c->slot_latent, slots, d, 1);
+    GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
 

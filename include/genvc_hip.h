@@ -145,7 +145,8 @@ int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride,
  * captured hipGraph with all step state on the device (no host sync per token; the reference
  * syncs at stream_generator.py:877).  Replaces GPT.generate / GPT.get_generator (gpt.py:594-621).
  *
- * Call after gvc_gpt_prefill(..., logits_out=NULL, latent_out=NULL, ...) on the same slots.  Per step i in [0,n_steps): samples token i from
+ * Call after gvc_gpt_prefill[_cached] on the same slots (its logits / latent are parked per slot, as are those of the last
+ * gvc_gpt_generate call: consecutive calls may batch different sets of slots).  Per step i in [0,n_steps): samples token i from
  * the current logits, stores it at tokens_out[b*tok_stride + i0 + i] and the latent that predicted
  * it at latents_out[(b*lat_stride + i0 + i)*d], then runs the decode step that consumes it.
  * ids / ids_len / finished as in gvc_sample (the caller initialises them from compute_embeddings).

@@ -421,3 +421,26 @@ def test_prefix_cache_with_a_long_segment_uses_the_tiled_path():
     a, _ = eng.decode_step(s0, tok)
     _, ref, _ = O.gpt_decode_step(wc, dims, cache, torch.tensor([7]), 1)
     np.testing.assert_allclose(a.cpu().numpy(), ref.numpy(), atol=1e-4)
+
+
+def test_generate_continues_from_a_prefill_that_returned_its_outputs(gold):
+    """the next-step logits / latent are parked per slot by every prefill, whether or not the caller asked for them"""
+    from genvc_amd.engine import sample_params
+    g = gold("gpt_tiny_b1")
+    dims, w, eng = setup(gcfg.TINY_MODEL_ARGS, int(g["seed"]))
+    cond, codes = inputs(g, dims)
+    dev = "cuda"
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    P, n = prefix.shape[1], g["tokens"].shape[1]
+    slots = torch.tensor([3], device=dev, dtype=torch.int32)
+    other = torch.tensor([0], device=dev, dtype=torch.int32)
+    eng.prefill(other, eng.prefix_embeddings(cond.to(dev) * 0.5, codes.to(dev).int()), want_outputs=False)   # unrelated staging
+    lg, lat = eng.prefill(slots, prefix, want_outputs=True)
+    ids = torch.ones(1, P + 1 + n + 8, device=dev, dtype=torch.int32)
+    ids[:, P] = dims["start_audio_token"]
+    ids_len = torch.full((1,), P + 1, device=dev, dtype=torch.int32)
+    fin = torch.zeros(1, device=dev, dtype=torch.int32)
+    toks = torch.zeros(1, n, device=dev, dtype=torch.int32)
+    lats = torch.zeros(1, n, dims["d_model"], device=dev)
+    eng.generate(slots, ids, ids_len, fin, sample_params(GREEDY, dims["num_audio_tokens"], dims["stop_audio_token"], 0), 0, n, toks, lats)
+    assert np.array_equal(toks.cpu().numpy(), g["tokens"])
