@@ -102,7 +102,8 @@ int gvc_gpt_prefill_cached(gvc_gpt* ctx, const int32_t* slots, int32_t B, const 
 
 /* One KV-cached decode step for B streams (gpt_inference.py:92-112):
  * x = mel_embedding[tok_in[b]] + mel_pos[pos(slot)], 30 blocks against the cache, double
- * LayerNorm, mel_head.  Appends K/V, advances the slot's length and mel position. */
+ * LayerNorm, mel_head.  Appends K/V, advances the slot's length and mel position.  For callers that sample themselves: the
+ * logits go to the caller only (gvc_gpt_generate continues a slot from its last prefill / generate, not from here). */
 int gvc_gpt_decode_step(gvc_gpt* ctx, const int32_t* slots, int32_t B, const int32_t* tok_in,
                         float* logits_out, float* latent_out, gvc_stream s);
 
