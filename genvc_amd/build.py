@@ -48,10 +48,12 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), sources()))
     objs = [o for o, _ in res]
     if any(c for _, c in res) or not os.path.exists(LIB):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB],
+        tmp = f"{LIB}.{os.getpid()}.tmp"       # linked aside and renamed: another rank waiting for LIB never maps a half-written file
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        os.replace(tmp, LIB)
         if verbose:
             print(f"built {LIB} ({sum(c for _, c in res)} objects recompiled)")
     elif verbose:
