@@ -91,6 +91,12 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
+// fp32 -> bf16, round to nearest even (finite inputs); the rule k_round_bf16 applies to the weights
+__device__ __forceinline__ unsigned short f32_to_bf16(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 // gelu_new of HF GPT-2 (tanh approximation), reference activation of GPT2MLP
 __device__ __forceinline__ float gelu_new(float x) {
     const float k = 0.7978845608028654f;  // sqrt(2/pi)

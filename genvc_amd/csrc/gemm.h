@@ -35,6 +35,7 @@ struct GemmEpi {
     int qkv;                 // 1 -> scatter mode, C is the q buffer [M][d]
     int d, n_head, head_dim, max_seq, T;
     float* kcache; float* vcache;
+    int kv_bf16;            // the cache holds bf16 (unsigned short) elements: k/v are rounded to nearest even on the way in
     const int32_t* slots;
     const int32_t* base_len;  // nullable: per-slot cached length; row t of batch b lands at position base_len[slot] + t
 };
@@ -70,7 +71,9 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, 
             const int pos = t + (e.base_len ? e.base_len[slot] : 0);
             const int h = c / e.head_dim, j = c - h * e.head_dim;
             float* cache = which == 1 ? e.kcache : e.vcache;
-            cache[(((size_t)slot * e.n_head + h) * e.max_seq + pos) * e.head_dim + j] = v;
+            const size_t at = (((size_t)slot * e.n_head + h) * e.max_seq + pos) * e.head_dim + j;
+            if (e.kv_bf16) reinterpret_cast<unsigned short*>(cache)[at] = f32_to_bf16(v);
+            else cache[at] = v;
         }
         return;
     }

@@ -205,7 +205,8 @@ struct gvc_gpt {
     std::vector<GptLayer> layers;
     std::map<std::string, int> bound;  // name -> 1 once bound
     int n_expected = 0;
-    float* kv = nullptr;              // [L][2][slots][H][max_seq][hd]
+    float* kv = nullptr;              // [L][2][slots][H][max_seq][hd], fp32 or (kv_bf16) bf16 elements
+    int kv_bf16 = 0;
     size_t kv_layer_stride = 0;       // floats per (layer, k|v)
     float *x = nullptr, *a = nullptr, *q = nullptr, *h = nullptr, *part = nullptr, *work = nullptr;
     long long work_cap = 0;
@@ -296,8 +297,9 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     gemm_init_attributes();
     GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
     if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
-    c->bf16 = D.weight_dtype == 1;
-    GVC_REQUIRE(D.weight_dtype == 0 || D.weight_dtype == 1, GVC_ERR_ARG, "weight_dtype must be 0 (fp32) or 1 (bf16)");
+    c->bf16 = D.weight_dtype >= 1;
+    c->kv_bf16 = D.weight_dtype == 2;
+    GVC_REQUIRE(D.weight_dtype >= 0 && D.weight_dtype <= 2, GVC_ERR_ARG, "weight_dtype must be 0 (fp32), 1 (bf16 weights) or 2 (bf16 weights + KV cache)");
     if (c->bf16) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->wh, (L * 12 * d * d + V * d + 64) * sizeof(unsigned short)));
         unsigned short* hq = c->wh;
@@ -317,7 +319,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     c->kv_layer_stride = (size_t)D.max_slots * D.n_head * D.max_seq * hd;
     const size_t rows = D.max_rows;
     c->work_cap = 8ll << 20;
-    if ((rc = alloc_f(&c->kv, 2 * L * c->kv_layer_stride)) || (rc = alloc_f(&c->x, rows * d)) ||
+    if ((rc = alloc_f(&c->kv, (c->kv_bf16 ? 1 : 2) * L * c->kv_layer_stride)) || (rc = alloc_f(&c->x, rows * d)) ||
         (rc = alloc_f(&c->a, rows * d)) || (rc = alloc_f(&c->q, rows * d)) || (rc = alloc_f(&c->h, rows * 4 * d)) ||
         (rc = alloc_f(&c->part, (size_t)D.max_slots * D.n_head * kAttnChunks * (hd + 4))) ||
         (rc = alloc_f(&c->work, (size_t)c->work_cap)) || (rc = alloc_f(&c->logits, (size_t)D.max_slots * V)) ||
@@ -558,6 +560,11 @@ static int gemv_init() {
     return gemv_allow_big_lds<PRO_LN2X, EPI_LOGITS>();
 }
 
+// K (which = 0) or V (1) cache of a layer; element size follows the context's KV dtype
+static float* kv_layer(const gvc_gpt* c, int layer, int which) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(c->kv) + (size_t)(2 * layer + which) * c->kv_layer_stride * (c->kv_bf16 ? 2 : 4));
+}
+
 static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     GemvArgs A;
     memset(&A, 0, sizeof(A));
@@ -574,19 +581,20 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     A.mel_emb = c->mel_emb;
     A.mel_pos_tab = c->mel_pos;
     A.prog = c->prog_active;
+    A.kv_bf16 = c->kv_bf16;
     return A;
 }
 
 static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s, bool wide = false) {
-    return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s, wide && c->hd == 256);
+    return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s, wide && c->hd == 256, c->kv_bf16 != 0);
 }
 
 static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
     AttnArgs T;
     memset(&T, 0, sizeof(T));
     T.q_stride = c->dm.d_model;
-    T.kbase = c->kv + (size_t)(2 * layer) * c->kv_layer_stride;
-    T.vbase = c->kv + (size_t)(2 * layer + 1) * c->kv_layer_stride;
+    T.kbase = kv_layer(c, layer, 0);
+    T.vbase = kv_layer(c, layer, 1);
     T.k_batch_stride = (long long)c->dm.n_head * c->dm.max_seq * c->hd;
     T.k_head_stride = (long long)c->dm.max_seq * c->hd;
     T.k_row_stride = c->hd;
@@ -628,8 +636,8 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
         A.Wt = ly.qkv_w; A.Wt16 = ly.qkv_h; A.bias = ly.qkv_b; A.N = 3 * d; A.K = d;
         A.ln_w = ly.ln1_w; A.ln_b = ly.ln1_b; A.embed = l == 0; A.tok_in = tok_in;
         A.out = qb;
-        A.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
-        A.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+        A.kcache = kv_layer(c, l, 0);
+        A.vcache = kv_layer(c, l, 1);
         if (!prof_skip(c, 0) && (rc = launch_gemv<PRO_LN, EPI_QKV>(c, A, B, s))) return rc;
 
         if (fused) {
@@ -640,7 +648,8 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
             F.max_seq = c->dm.max_seq; F.n_head = c->dm.n_head; F.d = d; F.scale = 1.0f / sqrtf((float)c->hd);
             F.Wp = ly.proj_w; F.part2 = c->part2 + (size_t)row0 * c->dm.n_head * d; F.prog = c->prog_active;
             if (!prof_skip(c, 1)) {
-                hipLaunchKernelGGL((k_attn_proj<256>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
+                if (c->kv_bf16) hipLaunchKernelGGL((k_attn_proj<256, 1>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
+                else hipLaunchKernelGGL((k_attn_proj<256, 0>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
                 GVC_LAUNCH_CHECK();
             }
             if (mlp_fused_ok(c)) {
@@ -808,8 +817,9 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
             G.Wt = ly.qkv_f; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
             G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
             G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
-            G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
-            G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+            G.e.kcache = kv_layer(c, l, 0);
+            G.e.vcache = kv_layer(c, l, 1);
+            G.e.kv_bf16 = c->kv_bf16;
             if ((rc = launch_gemm_skinny_ln(G, P, s))) return rc;
             if (l > 0) cur ^= 1;
 
@@ -848,8 +858,9 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
         G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
-        G.e.kcache = c->kv + (size_t)(2 * l) * c->kv_layer_stride;
-        G.e.vcache = c->kv + (size_t)(2 * l + 1) * c->kv_layer_stride;
+        G.e.kcache = kv_layer(c, l, 0);
+        G.e.vcache = kv_layer(c, l, 1);
+        G.e.kv_bf16 = c->kv_bf16;
         if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         AttnArgs At = gpt_attn_args(c, l, slots);

@@ -52,6 +52,7 @@ struct GemvArgs {
     float* out;                                 // q [B][d] / hidden [B][N] / logits [B][N]
     float* latent_out;                          // PRO_LN2X: [B][d]
     float* kcache; float* vcache;               // this layer's [slot][head][max_seq][hd]
+    int kv_bf16;                                // the cache holds bf16 elements (weight_dtype 2)
     int max_seq, max_mel_pos;
     const int32_t* slots;
     GptState st;
@@ -421,7 +422,9 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
                 const int h = c / A.head_dim;
                 const int j = c - h * A.head_dim;
                 float* cache = which == 1 ? A.kcache : A.vcache;
-                cache[(((size_t)slot * A.n_head + h) * A.max_seq + e_pos) * A.head_dim + j] = val;
+                const size_t at = (((size_t)slot * A.n_head + h) * A.max_seq + e_pos) * A.head_dim + j;
+                if (A.kv_bf16) reinterpret_cast<unsigned short*>(cache)[at] = f32_to_bf16(val);
+                else cache[at] = val;
             }
         } else if constexpr (EPI == EPI_RESID) {
             A.x[(size_t)(b * A.x_stride + A.x_off) * A.d + row] = e_res + val;
@@ -453,11 +456,11 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
 struct AttnArgs {
     const float* q;            // [rows][q_stride]; head h at + h*HD
     int q_stride;
-    const float* kbase;        // GPT: layer K cache [slot][head][max_seq][HD]; generic: see k_* strides
-    const float* vbase;
-    long long k_batch_stride;  // floats between batch elements (GPT: slot stride)
-    long long k_head_stride;   // floats between heads
-    int k_row_stride;          // floats between consecutive keys
+    const void* kbase;         // GPT: layer K cache [slot][head][max_seq][HD]; generic: see k_* strides.  fp32, or bf16 (KVB = 1)
+    const void* vbase;
+    long long k_batch_stride;  // elements between batch elements (GPT: slot stride)
+    long long k_head_stride;   // elements between heads
+    int k_row_stride;          // elements between consecutive keys
     int T;                     // rows per batch element (row = b*T + t)
     const int32_t* slots;      // nullable: batch index -> slot
     const int32_t* base_len;   // nullable: per-slot cached length before this call
@@ -473,7 +476,22 @@ struct AttnArgs {
 
 // NW = waves that share the keys of one (chunk, head, row): 4, or 16 for the batched decode rows (one new row over a
 // long cached context: 16 waves x U keys are requested per round trip instead of 4 x U)
-template <int HD, bool DIRECT, int NW = 4>
+// four consecutive cache elements of a key row: requested as stored (KVB = 1: bf16, 8 bytes per lane) and widened to fp32 only
+// where they are used -- a conversion next to the load would make every request wait for the one before it
+template <int KVB> struct KvRaw { typedef float4 T; };
+template <> struct KvRaw<1> { typedef uint2 T; };
+
+template <int KVB>
+__device__ __forceinline__ typename KvRaw<KVB>::T load_kv_raw(const char* p) {
+    return *reinterpret_cast<const typename KvRaw<KVB>::T*>(p);
+}
+__device__ __forceinline__ float4 kv_f4(const float4& r) { return r; }
+__device__ __forceinline__ float4 kv_f4(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int HD, bool DIRECT, int NW = 4, int KVB = 0>
 __global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const AttnArgs A) {
     if (NW == 4 && threadIdx.x >= 256) {      // optional prefetcher wave, see prefetch_wave()
         if (A.pf.base)
@@ -503,27 +521,28 @@ __global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const Att
     const int k1 = min(nk, k0 + cs);
 
     const float4 q4 = *reinterpret_cast<const float4*>(A.q + (size_t)row * A.q_stride + h * HD + dl);
-    const float* kp = A.kbase + bi * A.k_batch_stride + h * A.k_head_stride + dl;
-    const float* vp = A.vbase + bi * A.k_batch_stride + h * A.k_head_stride + dl;
+    constexpr int ES = KVB ? 2 : 4;            // bytes per cache element
+    const char* kp = reinterpret_cast<const char*>(A.kbase) + (bi * A.k_batch_stride + h * A.k_head_stride + dl) * ES;
+    const char* vp = reinterpret_cast<const char*>(A.vbase) + (bi * A.k_batch_stride + h * A.k_head_stride + dl) * ES;
 
     float m = -INFINITY, l = 0.f;
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int U = NW == 4 ? 4 : 8;
     for (int kb = k0 + wave * KPW + kl; kb < k1 + (U * NW * KPW); kb += U * NW * KPW) {
         if (kb - kl - wave * KPW >= k1) break;           // uniform per block iteration
-        float4 kv[U], vv[U];
+        typename KvRaw<KVB>::T kv[U], vv[U];
         float s[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int key = kb + u * NW * KPW;
             const bool ok = key < k1;
-            const size_t off = (size_t)(ok ? key : k0) * A.k_row_stride;
-            kv[u] = *reinterpret_cast<const float4*>(kp + off);
-            vv[u] = *reinterpret_cast<const float4*>(vp + off);
+            const size_t off = (size_t)(ok ? key : k0) * A.k_row_stride * ES;
+            kv[u] = load_kv_raw<KVB>(kp + off);
+            vv[u] = load_kv_raw<KVB>(vp + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float d = dot4(q4, kv[u]);
+            float d = dot4(q4, kv_f4(kv[u]));
             if constexpr (LPK == 64) d = wave_sum(d);
             else d = row16_sum(d);                         // LPK == 16
             s[u] = (kb + u * NW * KPW < k1) ? d * A.scale : -INFINITY;
@@ -537,9 +556,10 @@ __global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const Att
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float p = __expf(s[u] - mn);         // masked keys: exp(-inf) = 0
+                const float4 v4 = kv_f4(vv[u]);
                 l += p;
-                o.x = fmaf(p, vv[u].x, o.x); o.y = fmaf(p, vv[u].y, o.y);
-                o.z = fmaf(p, vv[u].z, o.z); o.w = fmaf(p, vv[u].w, o.w);
+                o.x = fmaf(p, v4.x, o.x); o.y = fmaf(p, v4.y, o.y);
+                o.z = fmaf(p, v4.z, o.z); o.w = fmaf(p, v4.w, o.w);
             }
             m = mn;
         }
@@ -589,7 +609,7 @@ constexpr int kFusedMaxKeys = 16;       // keys per wave
 
 struct AttnProjArgs {
     const float* q;            // [d] of the stream
-    const float* kcache; const float* vcache;   // layer base [slot][head][max_seq][HD]
+    const void* kcache; const void* vcache;     // layer base [slot][head][max_seq][HD], fp32 or bf16 (KVB = 1)
     const int32_t* slots; const int32_t* seq_len;
     int max_seq, n_head, d;
     float scale;
@@ -598,7 +618,7 @@ struct AttnProjArgs {
     int32_t* prog;
 };
 
-template <int HD>
+template <int HD, int KVB = 0>
 __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
     static_assert(HD == 256, "one key row = one float4 per lane");
     __shared__ float sc[8 * kFusedMaxKeys];
@@ -612,21 +632,22 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
     const int slot = A.slots[0];
     const int nk = A.seq_len[slot] + 1;                      // the key appended by this step included
     const float4 q4 = *reinterpret_cast<const float4*>(A.q + h * HD + lane * 4);
-    const size_t head_off = ((size_t)slot * A.n_head + h) * A.max_seq * HD + lane * 4;
-    const float* kp = A.kcache + head_off;
-    const float* vp = A.vcache + head_off;
-    float4 kr[kFusedMaxKeys], vr[kFusedMaxKeys];
+    constexpr int ES = KVB ? 2 : 4;
+    const size_t head_off = (((size_t)slot * A.n_head + h) * A.max_seq * HD + lane * 4) * ES;
+    const char* kp = reinterpret_cast<const char*>(A.kcache) + head_off;
+    const char* vp = reinterpret_cast<const char*>(A.vcache) + head_off;
+    typename KvRaw<KVB>::T kr[kFusedMaxKeys], vr[kFusedMaxKeys];
 #pragma unroll
     for (int j = 0; j < kFusedMaxKeys; ++j) {
         const int key = wave + 8 * j;            // wave-uniform: rows past the context are not requested at all
-        kr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key < nk) kr[j] = *reinterpret_cast<const float4*>(kp + (size_t)key * HD);
+        kr[j] = typename KvRaw<KVB>::T{};        // all-zero bits are 0.0f in both storage types
+        if (key < nk) kr[j] = load_kv_raw<KVB>(kp + (size_t)key * HD * ES);
     }
 #pragma unroll
     for (int j = 0; j < kFusedMaxKeys; ++j) {
         const int key = wave + 8 * j;
-        vr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key < nk) vr[j] = *reinterpret_cast<const float4*>(vp + (size_t)key * HD);
+        vr[j] = typename KvRaw<KVB>::T{};
+        if (key < nk) vr[j] = load_kv_raw<KVB>(vp + (size_t)key * HD * ES);
     }
     // this wave's two rows of the head's c_proj slice (streamed once, non-temporal)
     typedef float f32x4_nt __attribute__((ext_vector_type(4)));
@@ -638,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
 #pragma unroll
     for (int j = 0; j < kFusedMaxKeys; ++j) {
         const int key = wave + 8 * j;
-        s[j] = key < nk ? wave_sum(dot4(q4, kr[j])) * A.scale : -INFINITY;
+        s[j] = key < nk ? wave_sum(dot4(q4, kv_f4(kr[j]))) * A.scale : -INFINITY;
         if (lane == 0) sc[key] = s[j];
     }
     __syncthreads();
@@ -649,9 +670,10 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
 #pragma unroll
     for (int j = 0; j < kFusedMaxKeys; ++j) {
         const float p = __expf(s[j] - m);                    // masked keys: exp(-inf) = 0
+        const float4 v4 = kv_f4(vr[j]);
         l += p;
-        o.x = fmaf(p, vr[j].x, o.x); o.y = fmaf(p, vr[j].y, o.y);
-        o.z = fmaf(p, vr[j].z, o.z); o.w = fmaf(p, vr[j].w, o.w);
+        o.x = fmaf(p, v4.x, o.x); o.y = fmaf(p, v4.y, o.y);
+        o.z = fmaf(p, v4.z, o.z); o.w = fmaf(p, v4.w, o.w);
     }
     *reinterpret_cast<float4*>(&o_s[wave][lane * 4]) = o;
     if (lane == 0) l_s[wave] = l;
@@ -905,10 +927,17 @@ static __global__ __launch_bounds__(64) void k_step_prefetcher(const PrefetchEnt
 
 // host launcher shared by the GPT and Perceiver contexts
 static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& T, int chunks, int rows, bool direct,
-                                      hipStream_t s, bool wide = false) {
+                                      hipStream_t s, bool wide = false, bool kv_bf16 = false) {
     dim3 grid(chunks, n_head, rows);
     dim3 block(T.pf.base ? 320 : 256);
-    if (head_dim == 256) {
+    if (kv_bf16 && head_dim == 256) {
+        if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16, 1>), grid, dim3(1024), 0, s, T);
+        else if (direct) hipLaunchKernelGGL((k_attention<256, true, 4, 1>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<256, false, 4, 1>), grid, block, 0, s, T);
+    } else if (kv_bf16 && head_dim == 64) {
+        if (direct) hipLaunchKernelGGL((k_attention<64, true, 4, 1>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<64, false, 4, 1>), grid, block, 0, s, T);
+    } else if (head_dim == 256) {
         if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16>), grid, dim3(1024), 0, s, T);
         else if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
         else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);

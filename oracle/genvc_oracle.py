@@ -219,6 +219,10 @@ def gpt_blocks(w, dims, x, cache=None):
         q, k, v = qkv.split(d, dim=-1)
         sh = lambda t: t.reshape(B, T, H, hd).transpose(1, 2)
         q, k, v = sh(q), sh(k), sh(v)
+        if dims.get("kv_bf16"):
+            # the build's bf16 KV cache (include/genvc_hip.h: weight_dtype 2): every k and v is rounded to nearest even when
+            # it enters the cache, and attention reads the cache for the new rows too
+            k, v = k.to(torch.bfloat16).to(torch.float32), v.to(torch.bfloat16).to(torch.float32)
         if cache is not None:
             k = torch.cat([cache[l][0], k], dim=2)
             v = torch.cat([cache[l][1], v], dim=2)

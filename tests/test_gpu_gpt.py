@@ -275,20 +275,26 @@ def _round_bf16(w):
     return out
 
 
-@pytest.mark.parametrize("model_args,B,Tc,n", [(gcfg.TINY_MODEL_ARGS, 8, 75, 40), (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24)])
-def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n):
-    """BASELINE configs[3] direction: bf16 weight storage (fp32 math).  Because every path uses the same rounded
-    values, the oracle run on bf16-rounded weights is an exact reference: logits <= 1e-4, ids equal wherever the
-    oracle's own top-1/top-2 margin is not at rounding level."""
+@pytest.mark.parametrize("model_args,B,Tc,n,mode", [
+    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16"), (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16"),
+    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16_kv"), (gcfg.TINY_MODEL_ARGS, 3, 75, 70, "bf16_kv"),
+    (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16_kv"), (gcfg.DEFAULT_MODEL_ARGS, 8, 13, 12, "bf16_kv")])
+def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n, mode):
+    """BASELINE configs[3]: bf16 weight storage, optionally a bf16 KV cache (fp32 math).  Because every path uses the same
+    rounded values, the oracle run on bf16-rounded weights (and rounding k/v as they enter its cache) is an exact
+    reference: logits <= 1e-4, ids equal wherever the oracle's own top-1/top-2 margin is not at rounding level.
+    Covers the GEMV decode (B <= 4: fused short-context attention, then split-key past 128 keys), the rows path (B = 8)
+    and the prefill scatter."""
     from genvc_amd.engine import GptEngine
     from oracle import genvc_oracle as O
     _cache.clear()
     torch.cuda.empty_cache()
     dims = gcfg.gpt_dims(model_args)
     w = synth.make_weights(5, synth.gpt_weight_spec(dims), device="cuda")
-    eng = GptEngine(dims, max_slots=8, max_rows=2048, weight_dtype="bf16")
+    eng = GptEngine(dims, max_slots=8, max_rows=2048, weight_dtype=mode)
     eng.bind(w)
     wr = _round_bf16({k: v.cpu() for k, v in w.items()})
+    dims = dict(dims, kv_bf16=mode == "bf16_kv")
     cond = synth.uniform(51, "cond_latents", (B, 32, dims["d_model"]), 1.0)
     codes = synth.integers(51, "content_codes", (B, Tc), 256)
     _, toks, lats = run_generate(eng, dims, cond, codes, n)
@@ -304,7 +310,9 @@ def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n
             assert float(margins[b, int(bad[0])]) < 1e-3, (b, int(bad[0]), float(margins[b, int(bad[0])]))
     assert agree.float().mean() > 0.9
     first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
-    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-4)
+    # a bf16 cache is not reproducible to fp32 rounding: a k or v that sits within 1e-7 of a bf16 rounding boundary lands
+    # one bf16 ulp (0.4 %) apart in the two implementations, and 30 layers carry that to a few 1e-4 in the latents
+    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
     eng.close()
 
 
