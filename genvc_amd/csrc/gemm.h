@@ -43,6 +43,7 @@ struct GemmEpi {
 struct GemmArgs {
     const float* A; int lda; long long a_batch_stride;
     const float* Wt; int ldw; long long w_batch_stride;
+    int w_bf16;             // skinny kernels only: Wt is an FM16 copy of bf16 elements (unsigned short), widened in registers
     float* C; int ldc; long long c_batch_stride;
     int M, N, K;
     // implicit im2col for dilated convolutions over a time-major buffer: when conv_cin > 0, column k of A is
@@ -110,6 +111,7 @@ int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s);
 void gemm_init_attributes();        // raises dynamic-LDS limits; call once, outside stream capture
 // row-major [N][K] -> FM16
 __global__ void k_to_fm16(const float* src, float* dst, int N, int K);
+__global__ void k_to_fm16_bf16(const float* src, unsigned short* dst, int N, int K);   // src already rounded to bf16 values
 
 // chooses the split-K factor from the shape; `work_cap` = capacity of G.work in floats
 int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s);

@@ -135,7 +135,17 @@ int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NW>
+// a lane's four weight elements of a 16x16 FM16 block: requested as stored (WB = 1: bf16, 8 bytes), widened where the MFMA
+// consumes them (a conversion next to the load would serialise the requests)
+template <int WB> struct WRaw { typedef float4 T; };
+template <> struct WRaw<1> { typedef uint2 T; };
+__device__ __forceinline__ float4 w_f4(const float4& r) { return r; }
+__device__ __forceinline__ float4 w_f4(const uint2& u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <int MT, int NW, int WB = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float red_raw[];     // [NW][MT][256]
     float (*red)[MT][256] = reinterpret_cast<float (*)[MT][256]>(red_raw);
@@ -147,7 +157,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     (void)r; (void)g;
     const int kb16 = (blockIdx.y * kslice + wave * kw) >> 4;       // first 16-wide k block of this wave
     const int K16 = G.K >> 4;
-    const float* wp = G.Wt + ((size_t)(n0 >> 4) * K16 + kb16) * 256 + lane * 4;      // FM16 operands: a k step = +256 floats
+    typedef typename WRaw<WB>::T wraw_t;
+    // FM16 operands: a k step = +256 elements
+    const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)(n0 >> 4) * K16 + kb16) * 64 + lane;
     const float* ap[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) ap[t] = G.A + ((size_t)t * K16 + kb16) * 256 + lane * 4;
@@ -158,27 +170,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     // (the whole K range of a wave for the GenVC shapes), so a wave pays one memory round trip
     constexpr int U = 32 / (1 + MT) >= 8 ? 8 : (32 / (1 + MT) >= 4 ? 4 : 2);
     for (int ks = 0; ks < kw; ks += 16 * U) {
-        float4 w4[U], a4[U][MT];
+        wraw_t wr[U];
+        float4 a4[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = ks + 16 * u;
             const bool kin = k < kw;                   // rows past M hold stale data: their results are never stored
-            w4[u] = kin ? *reinterpret_cast<const float4*>(wp + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wr[u] = kin ? wp[k * 4] : wraw_t{};
 #pragma unroll
             for (int t = 0; t < MT; ++t)
                 a4[u][t] = kin ? *reinterpret_cast<const float4*>(ap[t] + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const float4 w4 = w_f4(wr[u]);
             // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].x, w4[u].x, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].x, w4.x, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].y, w4[u].y, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].y, w4.y, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].z, w4[u].z, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].z, w4.z, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].w, w4[u].w, acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].w, w4.w, acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -208,6 +222,19 @@ __global__ void k_to_fm16(const float* src, float* dst, int N, int K) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
         *reinterpret_cast<float4*>(dst + fm16_index(n, k, K)) = *reinterpret_cast<const float4*>(src + (size_t)n * K + k);
+    }
+}
+
+// the same permutation into bf16 storage; src holds values that are already bf16-representable (k_round_bf16 ran on it)
+__global__ void k_to_fm16_bf16(const float* src, unsigned short* dst, int N, int K) {
+    const size_t n4 = (size_t)N * K / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)n * K + k);
+        ushort4 o;
+        o.x = (unsigned short)(__float_as_uint(v.x) >> 16); o.y = (unsigned short)(__float_as_uint(v.y) >> 16);
+        o.z = (unsigned short)(__float_as_uint(v.z) >> 16); o.w = (unsigned short)(__float_as_uint(v.w) >> 16);
+        *reinterpret_cast<ushort4*>(dst + fm16_index(n, k, K)) = o;
     }
 }
 
@@ -309,7 +336,7 @@ int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* p
 // workgroups are still reading x_in).  Everything else as k_gemm_skinny<1, 8>: same per-element summation order, so the
 // result is bit-identical to k_ln_sum_rows_t followed by k_gemm_skinny.
 
-template <int NV>
+template <int NV, int WB = 0>
 __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const LnFuse P) {
     constexpr int K = 256 * NV, K16 = K / 16, NW = 8, kw = K / NW;           // kw = 128 (d = 1024) or 32 (d = 256)
     constexpr int U = kw / 16;
@@ -318,8 +345,9 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
     float (*red)[256] = reinterpret_cast<float (*)[256]>(sm + 16 * K);       // [NW][256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
-    float4 w4[U];
-    const float* wp = G.Wt + ((size_t)(n0 >> 4) * K16 + (wave * kw >> 4)) * 256 + lane * 4;
+    typedef typename WRaw<WB>::T wraw_t;
+    wraw_t w4[U];
+    const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)(n0 >> 4) * K16 + (wave * kw >> 4)) * 64 + lane;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = wave + 8 * rr;
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
             row_sum<NV>(P.x_in + (size_t)row * K, P.part, (size_t)row * K, (size_t)P.rows * K, P.SK, P.pbias, lane, v);
             if (rr == 1) {          // the weight fragments are requested once the prologue's own operands are on their way
 #pragma unroll
-                for (int u = 0; u < U; ++u) w4[u] = *reinterpret_cast<const float4*>(wp + u * 256);
+                for (int u = 0; u < U; ++u) w4[u] = wp[u * 64];
             }
             if (P.x_out && blockIdx.x == 0) {
 #pragma unroll
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
         } else {
             if (rr == 1) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) w4[u] = *reinterpret_cast<const float4*>(wp + u * 256);
+                for (int u = 0; u < U; ++u) w4[u] = wp[u * 64];
             }
 #pragma unroll
             for (int i = 0; i < NV; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -356,10 +384,11 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const float4 a4 = *reinterpret_cast<const float4*>(ap + u * 256);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4[u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4[u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4[u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4[u].w, acc, 0, 0, 0);
+        const float4 wv = w_f4(w4[u]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv.w, acc, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[wave][q * 64 + lane] = acc[q];
@@ -379,14 +408,17 @@ int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
                 "skinny gemm + LN: unsupported shape M=%d N=%d K=%d", G.M, G.N, G.K);
     G.SK = 1;
     const size_t lds = ((size_t)16 * G.K + 8 * 256) * sizeof(float);
-    if (G.K == 1024) hipLaunchKernelGGL(k_gemm_skinny_ln<4>, dim3(G.N / 16), dim3(512), lds, s, G, P);
-    else hipLaunchKernelGGL(k_gemm_skinny_ln<1>, dim3(G.N / 16), dim3(512), lds, s, G, P);
+    if (G.K == 1024 && G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny_ln<4, 1>), dim3(G.N / 16), dim3(512), lds, s, G, P);
+    else if (G.K == 1024) hipLaunchKernelGGL((k_gemm_skinny_ln<4, 0>), dim3(G.N / 16), dim3(512), lds, s, G, P);
+    else if (G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny_ln<1, 1>), dim3(G.N / 16), dim3(512), lds, s, G, P);
+    else hipLaunchKernelGGL((k_gemm_skinny_ln<1, 0>), dim3(G.N / 16), dim3(512), lds, s, G, P);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
 
 void gemm_init_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 }
 
 int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
@@ -401,8 +433,10 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
     const size_t lds = (size_t)(w8 ? 8 : 4) * MT * 256 * sizeof(float);
 #define GVC_SKINNY(mt)                                                                               \
     case mt:                                                                                         \
-        if (w8) hipLaunchKernelGGL((k_gemm_skinny<mt, 8>), grid, dim3(512), lds, s, G);              \
-        else hipLaunchKernelGGL((k_gemm_skinny<mt, 4>), grid, dim3(256), lds, s, G);                 \
+        if (w8 && G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny<mt, 8, 1>), grid, dim3(512), lds, s, G); \
+        else if (w8) hipLaunchKernelGGL((k_gemm_skinny<mt, 8, 0>), grid, dim3(512), lds, s, G);       \
+        else if (G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny<mt, 4, 1>), grid, dim3(256), lds, s, G); \
+        else hipLaunchKernelGGL((k_gemm_skinny<mt, 4, 0>), grid, dim3(256), lds, s, G);               \
         break;
     switch (MT) { GVC_SKINNY(1) GVC_SKINNY(2) GVC_SKINNY(3) GVC_SKINNY(4) GVC_SKINNY(5) GVC_SKINNY(6) GVC_SKINNY(7) GVC_SKINNY(8) }
 #undef GVC_SKINNY

@@ -309,10 +309,13 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
         c->head_h = hq;
     }
     if (c->skinny_prefill) {
-        if ((rc = alloc_f(&c->wfm, L * 12 * d * d))) { gvc_gpt_destroy(c); return rc; }
-        float* f = c->wfm;
+        // bf16-weights contexts keep the FM16 copies in bf16 too (half the bytes per pass; widened in registers)
+        const size_t es = c->bf16 ? 2 : 4;
+        if ((rc = alloc_f(&c->wfm, (L * 12 * d * d * es + 3) / 4))) { gvc_gpt_destroy(c); return rc; }
+        char* f = reinterpret_cast<char*>(c->wfm);
         for (auto& ly : c->layers) {
-            ly.qkv_f = f; f += 3 * d * d; ly.proj_f = f; f += d * d; ly.fc_f = f; f += 4 * d * d; ly.p2_f = f; f += 4 * d * d;
+            ly.qkv_f = reinterpret_cast<float*>(f); f += 3 * d * d * es; ly.proj_f = reinterpret_cast<float*>(f); f += d * d * es;
+            ly.fc_f = reinterpret_cast<float*>(f); f += 4 * d * d * es; ly.p2_f = reinterpret_cast<float*>(f); f += 4 * d * d * es;
         }
     }
 
@@ -400,8 +403,9 @@ static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N
         hipLaunchKernelGGL(k_round_bf16, dim3(1024), dim3(256), 0, s, dst, dst_bf16, (size_t)K * N);
         GVC_LAUNCH_CHECK();
     }
-    if (dst_fm16) {      // second copy in MFMA fragment order for the skinny prefill GEMM
-        hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, dst, dst_fm16, N, K);
+    if (dst_fm16) {      // second copy in MFMA fragment order for the skinny prefill GEMM (bf16 elements in a bf16-weights context)
+        if (dst_bf16) hipLaunchKernelGGL(k_to_fm16_bf16, dim3(1024), dim3(256), 0, s, dst, reinterpret_cast<unsigned short*>(dst_fm16), N, K);
+        else hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, dst, dst_fm16, N, K);
         GVC_LAUNCH_CHECK();
     }
     return GVC_OK;
@@ -814,7 +818,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
             memset(&P, 0, sizeof(P));
             P.x_in = X[cur]; P.ln_w = ly.ln1_w; P.ln_b = ly.ln1_b; P.rows = rows;
             if (l > 0) { P.part = part_p2; P.SK = SKP; P.pbias = c->layers[l - 1].p2_b; P.x_out = X[cur ^ 1]; }
-            G.Wt = ly.qkv_f; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+            G.Wt = ly.qkv_f; G.w_bf16 = c->bf16; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
             G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
             G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
             G.e.kcache = kv_layer(c, l, 0);
@@ -829,20 +833,20 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
             if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
             memset(&G, 0, sizeof(G));
-            G.A = c->a; G.lda = d; G.Wt = ly.proj_f; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d; G.work = part_proj;
+            G.A = c->a; G.lda = d; G.Wt = ly.proj_f; G.w_bf16 = c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d; G.work = part_proj;
             if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
 
             memset(&G, 0, sizeof(G));
             memset(&P, 0, sizeof(P));
             P.x_in = X[cur]; P.x_out = X[cur ^ 1]; P.part = part_proj; P.SK = SKP; P.pbias = ly.proj_b;
             P.ln_w = ly.ln2_w; P.ln_b = ly.ln2_b; P.rows = rows;
-            G.Wt = ly.fc_f; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+            G.Wt = ly.fc_f; G.w_bf16 = c->bf16; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
             G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = 1;
             if ((rc = launch_gemm_skinny_ln(G, P, s))) return rc;
             cur ^= 1;
 
             memset(&G, 0, sizeof(G));
-            G.A = c->h; G.lda = 4 * d; G.Wt = ly.p2_f; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d; G.work = part_p2;
+            G.A = c->h; G.lda = 4 * d; G.Wt = ly.p2_f; G.w_bf16 = c->bf16; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d; G.work = part_p2;
             if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
         }
         // fold the last layer's mlp partials into the residual stream, landing in c->x (what the head reads)
@@ -855,7 +859,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         GVC_LAUNCH_CHECK();
         GemmArgs G;
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
         G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
         G.e.kcache = kv_layer(c, l, 0);
@@ -870,7 +874,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.proj_f : ly.proj_w; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.proj_f : ly.proj_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
         if (skinny) {
             G.work = part_proj;
             if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
@@ -882,12 +886,12 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         }
         GVC_LAUNCH_CHECK();
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.fc_f : ly.fc_w; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.fc_f : ly.fc_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = skinny ? 1 : 0;
         if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->h; G.lda = 4 * d; G.Wt = skinny ? ly.p2_f : ly.p2_w; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
+        G.A = c->h; G.lda = 4 * d; G.Wt = skinny ? ly.p2_f : ly.p2_w; G.w_bf16 = skinny && c->bf16; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
         if (skinny) {
             G.work = part_p2;
             if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
