@@ -61,7 +61,7 @@ typedef struct gvc_gpt_dims {
     int32_t max_slots;    /* concurrent streams whose KV cache is resident */
     int32_t max_rows;     /* capacity (rows) of one prefill / latent re-pass call, all slots together */
     int32_t weight_dtype; /* 0: fp32 (reference numerics). 1: the c_attn/c_proj/c_fc/mlp c_proj/mel_head matrices are
-                             rounded to bf16 at bind time; the decode step streams the bf16 copy (half the HBM bytes),
+                             rounded to bf16 at bind time; the decode step and the skinny MFMA path stream bf16 copies (half the HBM bytes),
                              every product and accumulation stays fp32; KV cache and activations stay fp32 */
 } gvc_gpt_dims;
 
