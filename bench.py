@@ -43,29 +43,31 @@ KERNEL_NAMES = ["c_attn_gemv(ln1+qkv)", "attention+attn_c_proj(fused,head-split)
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def kernel_bytes(dims, which, S):
-    """algorithmic bytes of one launch of a decode-step kernel class at B=1"""
+def kernel_bytes(dims, which, S, wb=4, kvb=4):
+    """algorithmic bytes of one launch of a decode-step kernel class at B=1; wb / kvb = bytes per
+    streamed weight / KV-cache element (4, or 2 with --weights bf16 / bf16_kv); vectors and biases are always fp32"""
     d, V, H = dims["d_model"], dims["num_audio_tokens"], dims["n_head"]
     f = 4
     if which == 0:
-        return (3 * d * d + 3 * d + 2 * d + d + 3 * d) * f
+        return 3 * d * d * wb + (3 * d + 2 * d + d + d) * f + 2 * d * kvb
     if which == 1:     # fused attention + head-split attn c_proj (short-context variant): K/V rows + q + c_proj weights
-        return (2 * S * d + d + d * d + H * d) * f
+        return 2 * S * d * kvb + (d + H * d) * f + d * d * wb
     if which == 2:
-        return (d * d + d + 8 * H * (d // H + 4) + 2 * d) * f
+        return d * d * wb + (d + 8 * H * (d // H + 4) + 2 * d) * f
     if which == 3:
-        return (4 * d * d + 4 * d + 2 * d + d + 4 * d) * f
+        return 4 * d * d * wb + (4 * d + 2 * d + d + 4 * d) * f
     if which == 4:
-        return (4 * d * d + d + 4 * d + 2 * d) * f
-    return (V * d + V + 4 * d + d + V + d) * f
+        return 4 * d * d * wb + (d + 4 * d + 2 * d) * f
+    return V * d * wb + (V + 4 * d + d + V + d) * f
 
 
 class Workload:
-    def __init__(self, device, rank, streams=1):
+    def __init__(self, device, rank, streams=1, weight_dtype="fp32"):
         from genvc_amd.inference.model_init import model_init_synthetic
         self.dev = device
         self.S = S = streams
-        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=max(8, S))
+        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=max(8, S),
+                                                       weight_dtype=weight_dtype)
         m = self.model
         self.dims = m.gpt.dims()
         self.eng = m.gpt.engine
@@ -184,6 +186,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
+    ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv"],
+                    help="GPT weight / KV-cache storage (fp32 = headline configuration; bf16_kv with --streams 8 = BASELINE configs[3])")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,7 +217,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    wl = Workload(device, rank, args.streams)
+    wl = Workload(device, rank, args.streams, args.weights)
     for u in range(args.warmup):
         wl.utterance(u)
 
@@ -256,6 +260,8 @@ def main():
             wl.eng.prefill(s1, wl.eng.prefix_embeddings(wl.model.get_gpt_cond_latents(wl.ref[0], 24000),
                                                         torch.zeros(1, wl.Tc, device=device, dtype=torch.int32)), want_outputs=False)
         reps = 40
+        wb = 4 if args.weights == "fp32" else 2
+        kvb = 2 if args.weights == "bf16_kv" else 4
         fresh()
         whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)
         kern = []
@@ -268,7 +274,7 @@ def main():
             fresh()
             without_us, _ = wl.eng.time_kernel(16 + which, s1, tok, reps)
             kern.append({"kernel": KERNEL_NAMES[which], "avg_us": (whole_us - without_us) / per_step, "avg_us_launched_alone": iso,
-                         "launches_per_step": per_step, "bytes": kernel_bytes(wl.dims, which, S)})
+                         "launches_per_step": per_step, "bytes": kernel_bytes(wl.dims, which, S, wb, kvb)})
         # dominant = the weight-streaming GEMV with the largest share of the step (the fused attention launch is
         # L2/latency-bound, not an HBM stream, so it is listed but not used as the roofline kernel)
         cand = [i for i, k in enumerate(kern) if "gemv" in k["kernel"] and "head" not in k["kernel"]]
@@ -276,7 +282,7 @@ def main():
         achieved = kern[dom]["bytes"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.weights == "fp32":      # the PMC passes were taken on the fp32 build
             traffic = json.load(open(pmc)).get(kern[dom]["kernel"])
         n_utts = args.steps * world * args.streams
         ms_step = dt / args.steps * 1e3
@@ -284,13 +290,13 @@ def main():
             "metric": "utterances/s (streaming, 1 s chunks; with RTF and first-chunk latency)",
             "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.weights == "fp32" else "bf16 storage, f32 arithmetic", "data": "synthetic", "weights": args.weights,
             "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms, "streams_per_gpu": args.streams,
             "ms_per_utterance_device": utt_ms,
             "config": {"workload": ("GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])" if args.streams == 1
                                     else f"GenVC_small streaming, 1 s chunks, top_k=1, {args.streams} concurrent streams per GPU stepped together "
-                                         "(BASELINE configs[3] shape, fp32); one step = that many utterances"),
-                       "arch": "L=30 d=1024 H=4 V=1026 fp32, synthetic weights (train_genVC.py dims; no checkpoint ships)",
+                                         f"(BASELINE configs[3] shape, weights/KV: {args.weights}); one step = that many utterances"),
+                       "arch": f"L=30 d=1024 H=4 V=1026 {args.weights}, synthetic weights (train_genVC.py dims; no checkpoint ships)",
                        "utterance": "10 s source @16 kHz (10 chunks x 16000 samples -> 49 ContentVec frames -> 13 codes), 3 s reference @24 kHz",
                        "per_chunk": f"ContentVec (HuBERT-base) + DVAE/VQ + prefill {wl.P + 1} rows (chunks after the first: {wl.P + 1 - 32} rows, the 32 conditioning rows stay cached) + {STEPS_PER_CHUNK} decode steps; HiFi-GAN vocoder every {GROUP} tokens",
                        "excluded_from_timed_path": [],

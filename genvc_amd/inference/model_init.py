@@ -73,15 +73,15 @@ class GenVCModel(nn.Module):
         return torch.stack(embs).mean(dim=0).transpose(1, 2).contiguous()
 
 
-def build_model(config, device, content_extractor=None, hifigan=None, max_slots=8):
+def build_model(config, device, content_extractor=None, hifigan=None, max_slots=8, weight_dtype="fp32"):
     model = GenVCModel(config, content_extractor, hifigan)
-    return model, (lambda: _finish(model, device, max_slots))
+    return model, (lambda: _finish(model, device, max_slots, weight_dtype))
 
 
-def _finish(model, device, max_slots):
+def _finish(model, device, max_slots, weight_dtype="fp32"):
     model.eval()
     model.to(device)
-    model.gpt.init_gpt_for_inference(max_slots=max_slots)
+    model.gpt.init_gpt_for_inference(max_slots=max_slots, weight_dtype=weight_dtype)
     mb = max(2, max_slots)
     model.content_dvae.bind(max_batch=max(8, max_slots))
     if hasattr(model.content_extractor, "bind"):
@@ -106,11 +106,11 @@ def model_init(checkpoint_path, device, content_extractor=None, hifigan=None):
 
 
 @torch.inference_mode()
-def model_init_synthetic(config=None, seed=1, device="cuda", max_slots=8):
+def model_init_synthetic(config=None, seed=1, device="cuda", max_slots=8, weight_dtype="fp32"):
     """No checkpoint ships with the reference: deterministic synthetic weights of the same architecture."""
     from .. import synth
     config = config or gcfg.default_config()
-    model, finish = build_model(config, device, max_slots=max_slots)
+    model, finish = build_model(config, device, max_slots=max_slots, weight_dtype=weight_dtype)
     dims = gcfg.gpt_dims(config.model_args)
     w = {"gpt." + k: v for k, v in synth.make_weights(seed, synth.gpt_weight_spec(dims), device=device).items()}
     w.update({"content_dvae." + k: v for k, v in

@@ -102,8 +102,9 @@ class GPT(nn.Module):
                     code_stride_len=self.code_stride_len,
                     max_seq=self.max_prompt_tokens + self.max_mel_tokens + self.max_text_tokens + 1)   # gpt.py:198
 
-    def init_gpt_for_inference(self, kv_cache=True, use_deepspeed=False, max_slots=8, max_rows=4096):
-        """reference gpt.py:197-218: here = create the HIP context and repack the weights into it."""
+    def init_gpt_for_inference(self, kv_cache=True, use_deepspeed=False, max_slots=8, max_rows=4096, weight_dtype="fp32"):
+        """reference gpt.py:197-218: here = create the HIP context and repack the weights into it.
+        weight_dtype: "fp32" (reference numerics), "bf16" (bf16 weight storage) or "bf16_kv" (+ bf16 KV cache)."""
         if not kv_cache:
             raise NotImplementedError("the HIP path always uses the KV cache")
         if use_deepspeed:
@@ -111,7 +112,7 @@ class GPT(nn.Module):
         if self.engine is not None:
             self.engine.close()
         self.max_slots = max_slots
-        self.engine = GptEngine(self.dims(), max_slots=max_slots, max_rows=max_rows)
+        self.engine = GptEngine(self.dims(), max_slots=max_slots, max_rows=max_rows, weight_dtype=weight_dtype)
         sd = {k: v for k, v in self.state_dict().items() if not k.startswith("conditioning_perceiver.")}
         self.engine.bind(sd)
         self.conditioning_perceiver.bind()
