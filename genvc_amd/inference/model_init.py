@@ -94,11 +94,11 @@ def _finish(model, device, max_slots, weight_dtype="fp32"):
 
 
 @torch.inference_mode()
-def model_init(checkpoint_path, device, content_extractor=None, hifigan=None):
+def model_init(checkpoint_path, device, content_extractor=None, hifigan=None, weight_dtype="fp32"):
     ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
     config = gcfg.default_config()
     _merge(config, ckpt["config"])
-    model, finish = build_model(config, device, content_extractor, hifigan)
+    model, finish = build_model(config, device, content_extractor, hifigan, weight_dtype=weight_dtype)
     model.load_state_dict(ckpt["model"], strict=False)                   # model_init.py:22
     finish()
     print("Model initialized")

@@ -27,13 +27,15 @@ if __name__ == "__main__":
     parser.add_argument("--synthetic", action="store_true", help="deterministic synthetic weights instead of --model_path")
     parser.add_argument("--tiny", action="store_true", help="with --synthetic: the 2-layer test architecture")
     parser.add_argument("--save_tokens", type=str, default=None)
+    parser.add_argument("--weights", type=str, default="fp32", choices=["fp32", "bf16", "bf16_kv"],
+                        help="GPT weight / KV-cache storage on the GPU (fp32 = the reference's numerics)")
     args = parser.parse_args()
 
     if args.synthetic:
         from genvc_amd import config as gcfg
-        model, config = model_init_synthetic(gcfg.default_config(tiny=args.tiny), device=args.device)
+        model, config = model_init_synthetic(gcfg.default_config(tiny=args.tiny), device=args.device, weight_dtype=args.weights)
     else:
-        model, config = model_init(args.model_path, args.device)
+        model, config = model_init(args.model_path, args.device, weight_dtype=args.weights)
     model.config.top_k = args.top_k
     src_wav = load_audio(args.src_wav, model.content_sample_rate, device=args.device)
     ref_audio = load_audio(args.ref_audio, model.config.audio.sample_rate, device=args.device)

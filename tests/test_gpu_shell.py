@@ -173,6 +173,15 @@ def test_infer_cli_from_checkpoint_file(tmp_path):
     assert src.shape == (1, 24581) and ref.shape == (1, 98835)            # SURVEY 8d config (1) shapes
     d = synthesize_utt(m1, src, ref, return_details=True)
     assert torch.equal(torch.cat(d["codes"]).cpu(), tok["tokens"][0])
+    # the same command with bf16 weight + KV-cache storage (BASELINE configs[3]): runs, same format, a sane waveform
+    out2 = tmp_path / "converted_bf16.wav"
+    r = subprocess.run([sys.executable, os.path.join(root, "infer.py"), "--model_path", str(ck), "--src_wav", str(tmp_path / "src.wav"),
+                        "--ref_audio", str(tmp_path / "ref.wav"), "--output_path", str(out2), "--top_k", "1", "--weights", "bf16_kv",
+                        "--save_tokens", str(tmp_path / "tok2.pt")], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tok2 = torch.load(str(tmp_path / "tok2.pt"))
+    with wave.open(str(out2), "rb") as f:
+        assert f.getframerate() == 24000 and f.getnframes() == tok2["tokens"].shape[-1] * 1024
     _m.clear()
 
 
