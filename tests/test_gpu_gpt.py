@@ -452,3 +452,26 @@ def test_generate_continues_from_a_prefill_that_returned_its_outputs(gold):
     lats = torch.zeros(1, n, dims["d_model"], device=dev)
     eng.generate(slots, ids, ids_len, fin, sample_params(GREEDY, dims["num_audio_tokens"], dims["stop_audio_token"], 0), 0, n, toks, lats)
     assert np.array_equal(toks.cpu().numpy(), g["tokens"])
+
+
+def test_config4_batched_prefill_agrees_with_single_segments():
+    """BASELINE configs[4] shape at full size (prefill-heavy: 5 segments x 110 rows in ONE prefill, top_k=1): the batched
+    pass (tiled GEMM, 550 rows) and five single-segment passes (skinny path, 110 rows each) are different kernels, so the
+    size-independent property is agreement -- next-token logits / latents within 1e-4 and the same greedy continuation."""
+    dims, w, eng = setup(gcfg.DEFAULT_MODEL_ARGS, 1)
+    dev = "cuda"
+    B, Tc, n = 5, 75, 16
+    cond = synth.uniform(90, "cond_latents", (1, 32, dims["d_model"]), 1.0).expand(B, -1, -1).contiguous()     # one speaker
+    codes = synth.integers(90, "content_codes", (B, Tc), 256)
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    assert prefix.shape[1] == 109
+    slots = torch.arange(B, device=dev, dtype=torch.int32)
+    lg_b, lt_b = eng.prefill(slots, prefix)
+    _, toks_b, lats_b = run_generate(eng, dims, cond, codes, n)
+    for b in range(B):
+        lg_1, lt_1 = eng.prefill(slots[b:b + 1].contiguous(), prefix[b:b + 1].contiguous())
+        np.testing.assert_allclose(lg_1.cpu().numpy(), lg_b[b:b + 1].cpu().numpy(), atol=1e-4)
+        np.testing.assert_allclose(lt_1.cpu().numpy(), lt_b[b:b + 1].cpu().numpy(), atol=1e-4)
+        _, toks_1, lats_1 = run_generate(eng, dims, cond[b:b + 1], codes[b:b + 1], n)
+        assert torch.equal(toks_1[0], toks_b[b]), (b, toks_1[0], toks_b[b])
+        np.testing.assert_allclose(lats_1[0].numpy(), lats_b[b].numpy(), atol=1e-4)
