@@ -153,8 +153,9 @@ static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, lon
     }
 }
 
-// zero `front` rows before and `back` rows after the T live rows of every batch element of buf [B][front+T+back][C]
-static __global__ void k_hb_zero_pad(float* buf, int C, int T, int front, int back) {
+// zero `front` rows before and `back` rows after the T live rows of every batch element of buf [B][front+T+back][C], and
+// the live rows whose frame is padding (fairseq TransformerEncoder.extract_features: x[padding_mask] = 0 ahead of pos_conv)
+static __global__ void k_hb_zero_pad(float* buf, int C, int T, int front, int back, const int32_t* fmask) {
     const int b = blockIdx.y;
     float* base = buf + (size_t)b * (front + T + back) * C;
     const size_t nf = (size_t)front * C, nb = (size_t)back * C;
@@ -162,6 +163,23 @@ static __global__ void k_hb_zero_pad(float* buf, int C, int T, int front, int ba
         if (i < nf) base[i] = 0.f;
         else base[(size_t)(front + T) * C + (i - nf)] = 0.f;
     }
+    for (int t = blockIdx.x; t < T; t += gridDim.x) {
+        if (!fmask[b * T + t]) continue;                       // uniform per workgroup
+        for (int i = threadIdx.x; i < C; i += blockDim.x) base[(size_t)(front + t) * C + i] = 0.f;
+    }
+}
+
+// The reference's padding mask (layers/content_processor.py:24: padding_mask = (wav == 0)) reduced to frames the way
+// fairseq's HubertModel.forward_padding_mask does it: the trailing T % F samples are dropped, the rest is viewed as
+// [F][T / F] and a frame is padding when ALL samples of its chunk are exactly zero.  One wave per frame.
+static __global__ __launch_bounds__(64) void k_hb_frame_mask(const float* wav, int32_t* fmask, int T, int F) {
+    const int f = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int chunk = T / F;
+    const float* p = wav + (size_t)b * T + (size_t)f * chunk;
+    int nz = 0;
+    for (int i = lane; i < chunk; i += 64) nz |= (p[i] != 0.f);
+    nz = __any(nz);
+    if (lane == 0) fmask[b * F + f] = nz ? 0 : 1;
 }
 
 // Non-causal multi-head attention, head_dim 64, fp32.  qkv [B*T][3E] (q | k | v, head h at columns h*64), out [B*T][E].
@@ -172,7 +190,9 @@ static __global__ void k_hb_zero_pad(float* buf, int C, int T, int front, int ba
 // B-operand layout of the second product when its k-step i is mapped to keys {key0 + 4g + i}.  The d index of the
 // first product is permuted (d = 16s + 4g + comp) and the row index of O^T is permuted (row m of tile mt <-> d = 4m + mt)
 // so that every fragment load is a float4.
-static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, float* out, int T, int E, float scale, int out_fm16) {
+// fmask [B][T]: keys of padding frames are excluded (fairseq MultiheadAttention key_padding_mask: scores -> -inf)
+static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, float* out, int T, int E, float scale, int out_fm16,
+                                                            const int32_t* fmask) {
     __shared__ float sm[4][16], sl[4][16];
     __shared__ __attribute__((aligned(16))) float so[4][16][68];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -199,10 +219,12 @@ static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, f
         float4 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const float4*>(kbase + (size_t)kr * ld + 16 * s + 4 * g);
+        int kmask[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vr = min(key0 + 4 * g + i, T - 1);
             vf[i] = *reinterpret_cast<const float4*>(vbase + (size_t)vr * ld + 4 * r);
+            kmask[i] = fmask[b * T + vr];
         }
         hb_f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -216,16 +238,18 @@ static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, f
         float tmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            p[i] = (key0 + 4 * g + i < T) ? st[i] : -INFINITY;
+            p[i] = (key0 + 4 * g + i < T && !kmask[i]) ? st[i] : -INFINITY;
             tmax = fmaxf(tmax, p[i]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));        // finite: key0 < T
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float mnew = fmaxf(m, tmax);
-        const float alpha = expf(m - mnew);
+        // a tile (or everything so far) made of padding keys only leaves mnew at -inf: nothing to add, nothing to rescale
+        const bool none = mnew == -INFINITY;
+        const float alpha = none ? 1.0f : expf(m - mnew);
         float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { p[i] = expf(p[i] - mnew); psum += p[i]; }
+        for (int i = 0; i < 4; ++i) { p[i] = none ? 0.f : expf(p[i] - mnew); psum += p[i]; }
         l = l * alpha + psum;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) o[mt] *= alpha;
@@ -255,7 +279,7 @@ static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, f
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float f = expf(sm[w][qr] - M);
+            const float f = sm[w][qr] == -INFINITY ? 0.f : expf(sm[w][qr] - M);
             L += sl[w][qr] * f;
             const float4 ov = *reinterpret_cast<const float4*>(&so[w][qr][dc]);
             acc.x += ov.x * f; acc.y += ov.y * f; acc.z += ov.z * f; acc.w += ov.w * f;
@@ -288,6 +312,7 @@ struct gvc_hubert {
     int n_expected = 0;
     float *act[2] = {nullptr, nullptr};           // conv activations (ping-pong)
     float *part = nullptr, *stats = nullptr;
+    int32_t* fmask = nullptr;                     // [B][frames]: 1 = padding frame (all samples of its chunk are zero)
     float *xp = nullptr, *x = nullptr, *qkv = nullptr, *att = nullptr, *hbuf = nullptr, *tmp = nullptr, *work = nullptr;
     long long work_cap = 0;
     int max_frames = 0, max_t0 = 0;
@@ -383,6 +408,7 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
     for (int i = 0; i < 2 && !rc; ++i) rc = hb_alloc(c, &c->act[i], B * maxact);
     if (!rc) rc = hb_alloc(c, &c->part, B * (size_t)cdiv(c->max_t0, kC0Chunk) * D.conv_dim[0] * 2);
     if (!rc) rc = hb_alloc(c, &c->stats, B * D.conv_dim[0] * 2);
+    if (!rc) rc = hb_alloc(c, reinterpret_cast<float**>(&c->fmask), B * F);
     if (!rc) rc = hb_alloc(c, &c->xp, B * (F + kp) * E);
     if (!rc) rc = hb_alloc(c, &c->x, B * F * E);
     if (!rc) rc = hb_alloc(c, &c->tmp, B * F * E);
@@ -531,8 +557,6 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->act[cur], (long long)F * Cl, c->act[cur ^ 1],
                        (long long)F * Cl, F, Cl, c->feat_ln.w, c->feat_ln.b);
     GVC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_hb_zero_pad, dim3(64, B), dim3(256), 0, s, c->xp, E, F, c->pad_front, c->pad_back);
-    GVC_LAUNCH_CHECK();
     {
         GemmArgs G;
         memset(&G, 0, sizeof(G));
@@ -543,6 +567,9 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
         G.e.bias = c->proj.b;
         if ((rc = launch_gemm_cap(G, B, c->work_cap, s))) return rc;
     }
+    // conv padding rows, and the rows of padding frames, are zero from here on
+    hipLaunchKernelGGL(k_hb_zero_pad, dim3(64, B), dim3(256), 0, s, c->xp, E, F, c->pad_front, c->pad_back, c->fmask);
+    GVC_LAUNCH_CHECK();
     // tmp = x + gelu(pos_conv(x) + bias): one batched GEMM per batch element, batch = group
     for (int b = 0; b < B; ++b) {
         GemmArgs G;
@@ -584,7 +611,7 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
         for (int l = 0; l < D.n_layers; ++l) {
             const HbLayer& L = c->layers[l];
             if ((rc = sk_gemm(L.qkv, c->xf, c->qkv, ACT_NONE, 0, 1))) return rc;
-            hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->af, F, E, 0.125f, 1);
+            hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->af, F, E, 0.125f, 1, c->fmask);
             GVC_LAUNCH_CHECK();
             if ((rc = sk_gemm(L.out, c->af, c->tmp, ACT_NONE, 0, sk_out, c->x))) return rc;
             post_ln(L.out, L.ln1, sk_out);
@@ -602,7 +629,7 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     for (int l = 0; l < D.n_layers; ++l) {
         const HbLayer& L = c->layers[l];
         if ((rc = hb_linear(c, L.qkv, c->x, c->qkv, rows, ACT_NONE, nullptr, s))) return rc;
-        hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->att, F, E, 0.125f, 0);
+        hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->att, F, E, 0.125f, 0, c->fmask);
         GVC_LAUNCH_CHECK();
         if ((rc = hb_linear(c, L.out, c->att, c->tmp, rows, ACT_NONE, c->x, s))) return rc;
         hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
@@ -637,6 +664,8 @@ extern "C" int gvc_hubert_forward(gvc_hubert* c, const float* wav, int32_t B, in
     const int T0 = hb_frames(D, T, 1), C0 = D.conv_dim[0], k0 = D.conv_kernel[0], s0 = D.conv_stride[0];
     hipLaunchKernelGGL(k_hb_conv0, dim3(cdiv(T0, kC0Chunk), cdiv(C0, 256), B), dim3(256), ((kC0Chunk - 1) * s0 + k0) * sizeof(float), s, wav,
                        c->conv0_w, c->act[0], c->part, T, T0, C0, k0, s0);
+    GVC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hb_frame_mask, dim3(F, B), dim3(64), 0, s, wav, c->fmask, T, F);
     GVC_LAUNCH_CHECK();
     int rc;
     if (!c->use_graph) {

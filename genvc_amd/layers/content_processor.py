@@ -8,8 +8,9 @@ built as HIP kernels behind `gvc_hubert_*` (genvc_amd/csrc/hubert.hip).  This fi
   * `contentvec_frames(T)`: the frame count of the conv stack (k=[10,3,3,3,3,2,2], s=[5,2,2,2,2,2,2]);
   * `ContentvecExtractor`: the reference's interface (`.model`, `extract_content_features(wavs[B,T]) -> [B,T50,256]`)
     whose `.model` holds the fairseq-named parameters, so a GenVC checkpoint's `content_extractor.model.*` keys load
-    with `load_state_dict`.  The reference's `wav == 0` padding mask only marks frames whose whole receptive field is
-    exactly zero (zero-padded batches); this path handles un-padded audio;
+    with `load_state_dict`.  The reference's `padding_mask = (wav == 0)` (:24) is applied inside `gvc_hubert_forward` with
+    fairseq's frame reduction (a frame whose whole chunk of samples is exactly zero is padding: zeroed ahead of the positional
+    conv, excluded as an attention key) -- it matters for the harness's zero-padded tail segment and for digital silence;
   * `SyntheticContentExtractor`: a cheap deterministic stand-in kept for plumbing tests (NOT ContentVec).
 """
 import torch

@@ -275,8 +275,10 @@ int gvc_resample(const float* x, int32_t B, int32_t T, int32_t orig_sr, int32_t 
  * ContentVecExtractor.extract_content_features (layers/content_processor.py:17-31):
  *   fairseq HubertModel.extract_features(source=wav, output_layer=n_layers)[0] -> final_proj
  * i.e. 7-layer conv extractor (GroupNorm + GELU on layer 0) -> LayerNorm -> post_extract_proj -> x + GELU(grouped
- * positional conv) -> LayerNorm -> n_layers post-LN transformer layers -> final_proj.  No-padding path: the
- * reference's `wav == 0` padding mask is all-false for real audio and is not modelled.
+ * positional conv) -> LayerNorm -> n_layers post-LN transformer layers -> final_proj.  The reference's
+ * `padding_mask = (wav == 0)` (content_processor.py:24) is derived from `wav` by the library itself, with fairseq's
+ * reduction to frames (trailing samples % frames dropped, a frame is padding when every sample of its chunk is exactly
+ * zero): padding frames are zeroed ahead of the positional conv and their keys are excluded from every attention.
  * Weight names are fairseq's (the keys under `content_extractor.model.` in a GenVC checkpoint), except the
  * weight-normed positional conv, bound folded as "encoder.pos_conv.0.weight" [E, E/groups, k] (g * v / |v|, dim=2).
  * ------------------------------------------------------------------------------------------ */

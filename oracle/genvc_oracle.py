@@ -367,11 +367,25 @@ def generate(w, dims, cond_latents, codes, sampling, max_new=None, seed=0, stop_
 # (layers/content_processor.py:17-31).  fairseq is neither vendored nor installed: the arithmetic below restates the
 # HuBERT-base forward (conv extractor with GroupNorm on layer 0, post-LN encoder, weight-normed grouped positional
 # conv) and is pinned against HuggingFace's HubertModel -- the architecture fairseq checkpoints convert to -- by
-# oracle/make_golden.py.  The reference's `wav == 0` padding mask (quirk 10) is not modelled: no-padding path only.
+# oracle/make_golden.py.  The reference's `padding_mask = (wav == 0)` (content_processor.py:24) is followed through
+# fairseq's semantics restated from the library's published code (HubertModel.forward_padding_mask: drop the trailing
+# T % F samples, view [F][T // F], a frame is padding when ALL its samples are zero; TransformerEncoder.extract_features:
+# x[padding] = 0 ahead of pos_conv; MultiheadAttention key_padding_mask: scores of padding keys -> -inf).  That part has
+# no pin at all (HF's HubertModel masks by length, not by zeros): parity unpinned.  With no all-zero chunk in the input
+# the mask is empty and the function is the one the HF goldens pin.
 # ---------------------------------------------------------------------------
 
-def hubert_extract_features(w, cfg, wav, prefix=""):
-    """wav [B,T] -> [B,T50,final_dim]"""
+def hubert_frame_padding_mask(wav, n_frames):
+    """(wav == 0) [B,T] -> bool [B,F]; fairseq HubertModel.forward_padding_mask"""
+    pm = wav == 0
+    extra = pm.shape[1] % n_frames
+    if extra > 0:
+        pm = pm[:, :-extra]
+    return pm.reshape(pm.shape[0], n_frames, -1).all(-1)
+
+
+def hubert_extract_features(w, cfg, wav, prefix="", padding_mask=True):
+    """wav [B,T] -> [B,T50,final_dim]; padding_mask=False: the mask-free forward (what HF's HubertModel computes)"""
     g = lambda n: w[prefix + n]
     x = wav[:, None, :]
     for i, (c, k, s) in enumerate(cfg["conv_layers"]):
@@ -382,6 +396,11 @@ def hubert_extract_features(w, cfg, wav, prefix=""):
     x = x.transpose(1, 2)
     x = F.layer_norm(x, (x.shape[-1],), g("layer_norm.weight"), g("layer_norm.bias"), 1e-5)
     x = F.linear(x, g("post_extract_proj.weight"), g("post_extract_proj.bias"))
+    pm = hubert_frame_padding_mask(wav, x.shape[1]) if padding_mask else None
+    if pm is not None and not bool(pm.any()):
+        pm = None
+    if pm is not None:
+        x = x.masked_fill(pm[:, :, None], 0.0)
     v, gg = g("encoder.pos_conv.0.weight_v"), g("encoder.pos_conv.0.weight_g")
     wpc = gg * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()                  # weight_norm(dim=2)
     kp = cfg["pos_conv_kernel"]
@@ -400,7 +419,10 @@ def hubert_extract_features(w, cfg, wav, prefix=""):
         q = sh(F.linear(x, g(p + "self_attn.q_proj.weight"), g(p + "self_attn.q_proj.bias")))
         k = sh(F.linear(x, g(p + "self_attn.k_proj.weight"), g(p + "self_attn.k_proj.bias")))
         vv = sh(F.linear(x, g(p + "self_attn.v_proj.weight"), g(p + "self_attn.v_proj.bias")))
-        a = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5, dim=-1)
+        sc = torch.matmul(q, k.transpose(-1, -2)) * hd ** -0.5
+        if pm is not None:
+            sc = sc.masked_fill(pm[:, None, None, :], float("-inf"))
+        a = torch.softmax(sc, dim=-1)
         o = torch.matmul(a, vv).transpose(1, 2).reshape(B, T, e)
         x = x + F.linear(o, g(p + "self_attn.out_proj.weight"), g(p + "self_attn.out_proj.bias"))
         x = F.layer_norm(x, (e,), g(p + "self_attn_layer_norm.weight"), g(p + "self_attn_layer_norm.bias"), 1e-5)

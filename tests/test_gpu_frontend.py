@@ -168,3 +168,37 @@ def test_hubert_batches_agree_with_single_items():
         for b in range(B):
             np.testing.assert_allclose(got[b].cpu().numpy(), solo[b][0].cpu().numpy(), atol=2e-5)
     eng.close()
+
+
+def test_hubert_padding_mask_follows_zero_runs():
+    """content_processor.py:24: padding_mask = (wav == 0).  Frames whose whole chunk of samples is exactly zero are padding
+    (fairseq forward_padding_mask): their rows are zeroed ahead of the positional conv and their keys are excluded from
+    every attention.  Cases: the harness's zero-padded tail segment (5120 samples, 2000 of them real), an interior run of
+    digital silence, a batch whose items have different masks, and isolated zero samples (no frame is padding)."""
+    from genvc_amd.engine import HubertEngine
+    from oracle import genvc_oracle as O
+    for c, T in ((gcfg.TINY_HUBERT, 16000), (gcfg.DEFAULT_HUBERT, 16000)):
+        w = synth.make_weights(23, synth.hubert_weight_spec(c), device=DEV)
+        wcpu = {k: v.cpu() for k, v in w.items()}
+        eng = HubertEngine(c, max_batch=2, max_samples=T)
+        eng.bind(w)
+        tail = torch.zeros(1, 5120)
+        tail[:, :2000] = synth.synth_audio(41, "tail", 2000)
+        silence = synth.synth_audio(42, "mid", T).clone()
+        silence[:, 5000:9000] = 0.0                                   # covers whole chunks of 326 samples -> padding frames
+        sparse = synth.synth_audio(43, "sp", T).clone()
+        sparse[:, ::7] = 0.0                                          # zeros, but no all-zero chunk
+        for wav in (tail, silence, torch.cat([silence, sparse], 0), sparse):
+            F_ = eng.frames(wav.shape[1])
+            pm = O.hubert_frame_padding_mask(wav, F_)
+            ref = O.hubert_extract_features(wcpu, c, wav)
+            got = eng.forward(wav.to(DEV)).cpu()
+            np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=5e-4)
+            nomask = O.hubert_extract_features(wcpu, c, wav, padding_mask=False)
+            if bool(pm.any()):                                        # the mask matters: the mask-free forward is far away
+                assert float((nomask - ref).abs().max()) > 1e-2
+            else:
+                assert torch.equal(nomask, ref)
+        assert int(O.hubert_frame_padding_mask(tail, eng.frames(5120)).sum()) >= 8
+        assert int(O.hubert_frame_padding_mask(silence, 49).sum()) >= 10
+        eng.close()

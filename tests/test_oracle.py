@@ -161,3 +161,22 @@ def test_hubert_restatement_vs_hf(gold):
             ref = g[f"{tag}_feat_{B}_{T}"]
             assert feat.shape[:2] == ref.shape[:2] and feat.shape[-1] == 256
             np.testing.assert_allclose(feat.numpy()[:, :, :ref.shape[-1]], ref, atol=2e-4)
+
+
+def test_hubert_padding_mask_semantics():
+    """content_processor.py:24 + fairseq forward_padding_mask: trailing T % F samples dropped, a frame is padding when its
+    whole chunk is zero; an input without an all-zero chunk takes the mask-free path bit for bit"""
+    from genvc_amd import config as gcfg
+    c = gcfg.TINY_HUBERT
+    w = synth.make_weights(23, synth.hubert_weight_spec(c), device="cpu")
+    tail = torch.zeros(1, 5120)
+    tail[:, :2000] = synth.synth_audio(41, "tail", 2000)
+    pm = O.hubert_frame_padding_mask(tail, 15)                          # chunk = 341 samples, 5 dropped
+    assert pm.int().tolist() == [[0] * 6 + [1] * 9]                     # frame 5 holds samples 1705..2045: 295 of them real
+    a = O.hubert_extract_features(w, c, tail)
+    assert bool(torch.isfinite(a).all())
+    assert float((a - O.hubert_extract_features(w, c, tail, padding_mask=False)).abs().max()) > 1e-2
+    sparse = synth.synth_audio(43, "sp", 16000).clone()
+    sparse[:, ::7] = 0.0
+    assert not bool(O.hubert_frame_padding_mask(sparse, 49).any())
+    assert torch.equal(O.hubert_extract_features(w, c, sparse), O.hubert_extract_features(w, c, sparse, padding_mask=False))
