@@ -9,6 +9,7 @@
 
 #include "gemm.h"
 #include "gpt_kernels.h"
+#include "persist_kernel.h"
 #include "sampler.h"
 
 namespace gvc {
@@ -244,6 +245,14 @@ struct gvc_gpt {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* dbg = nullptr; // GVC_DEBUG_STAMPS: [launch][8] in-kernel timestamps of the eager decode step
     int dbg_n = 0;
+    // one-launch decode step (persist_kernel.h), one stream
+    int persist = 1;                  // GVC_PERSIST=0: launch-per-phase decode
+    PersistLayer* p_layers = nullptr; // device table of per-layer pointers
+    pu64* p_gran = nullptr;           // granule buffers of the in-kernel hand-offs
+    unsigned* p_epoch = nullptr;      // [0] step epoch, [1] arrival counter
+    unsigned long long* p_dbg = nullptr;   // GVC_PERSIST_STAMPS: wall-clock stamps of workgroup 0
+    int p_ring_slots = 0, p_ascr = 0;
+    size_t p_lds = 0;
 };
 
 static int gemv_init();
@@ -357,6 +366,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
     GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    if (getenv("GVC_PERSIST")) c->persist = atoi(getenv("GVC_PERSIST"));
     if (getenv("GVC_DEBUG_STAMPS")) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->dbg, 4096 * 8 * sizeof(unsigned long long)));
         GVC_CHECK_HIP(hipMemset(c->dbg, 0, 4096 * 8 * sizeof(unsigned long long)));
@@ -377,6 +387,8 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->seam_gran) hipFree(c->seam_gran);
     if (c->xalt) hipFree(c->xalt);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
+    for (void* p : {(void*)c->p_layers, (void*)c->p_gran, (void*)c->p_epoch, (void*)c->p_dbg})
+        if (p) hipFree(p);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->slot_logits, (void*)c->slot_latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
                     (void*)c->gen_call})
@@ -627,6 +639,77 @@ static bool mlp_fused_ok(const gvc_gpt* c) {
     return c->fuse_mlp && !c->bf16 && (d == 1024 || d == 256) && c->dm.n_head <= 16 && d / 4 <= c->n_cu;
 }
 
+// ---------------------------------------------------------------------------------------------
+// one-launch decode step (persist_kernel.h)
+// ---------------------------------------------------------------------------------------------
+template <int ND>
+static int persist_set_attr(size_t lds) {
+    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_decode_persist<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return GVC_OK;
+}
+
+// one stream, fp32 weights and cache, d in {256, 512, 1024}, head_dim in {64, 128, 256}, a full MI355X (one workgroup per CU)
+static bool persist_ok(const gvc_gpt* c, int B) {
+    const int d = c->dm.d_model;
+    return c->persist && B == 1 && !c->bf16 && c->n_cu >= kPG && (d == 256 || d == 512 || d == 1024) &&
+           (c->hd == 64 || c->hd == 128 || c->hd == 256) && c->dm.n_layer < 500;
+}
+
+// buffers and the per-layer pointer table; called outside stream capture (synchronous copies)
+static int persist_prepare(gvc_gpt* c) {
+    if (c->p_layers) return GVC_OK;
+    const int d = c->dm.d_model, L = c->dm.n_layer, H = c->dm.n_head;
+    std::vector<PersistLayer> t(L);
+    for (int l = 0; l < L; ++l) {
+        const GptLayer& ly = c->layers[l];
+        PersistLayer& p = t[l];
+        p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_w = ly.qkv_w; p.qkv_b = ly.qkv_b; p.proj_w = ly.proj_w; p.proj_b = ly.proj_b;
+        p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b; p.fc_w = ly.fc_w; p.fc_b = ly.fc_b; p.p2_w = ly.p2_w; p.p2_b = ly.p2_b;
+        p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
+    }
+    const size_t ngran = (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + d + 4 * d + d;
+    GVC_CHECK_HIP(hipMalloc((void**)&c->p_gran, ngran * sizeof(pu64)));
+    GVC_CHECK_HIP(hipMemset(c->p_gran, 0, ngran * sizeof(pu64)));
+    GVC_CHECK_HIP(hipMalloc((void**)&c->p_epoch, 4 * sizeof(unsigned)));
+    GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned)));
+    if (getenv("GVC_PERSIST_STAMPS")) {
+        GVC_CHECK_HIP(hipMalloc((void**)&c->p_dbg, (size_t)2 * (5 * L + 8) * sizeof(unsigned long long)));
+        GVC_CHECK_HIP(hipMemset(c->p_dbg, 0, (size_t)2 * (5 * L + 8) * sizeof(unsigned long long)));
+    }
+    c->p_ascr = 3 * c->hd + 1024 + 2 * kPCW * (256 / c->hd);
+    const size_t other = ((size_t)4 * d + d + c->p_ascr) * sizeof(float) + 64;
+    c->p_ring_slots = 8;
+    while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > 160 * 1024) c->p_ring_slots >>= 1;
+    c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
+    int rc;
+    if ((rc = persist_set_attr<1>(c->p_lds)) || (rc = persist_set_attr<2>(c->p_lds)) || (rc = persist_set_attr<4>(c->p_lds))) return rc;
+    PersistLayer* dev = nullptr;
+    GVC_CHECK_HIP(hipMalloc((void**)&dev, L * sizeof(PersistLayer)));
+    GVC_CHECK_HIP(hipMemcpy(dev, t.data(), L * sizeof(PersistLayer), hipMemcpyHostToDevice));
+    c->p_layers = dev;
+    return GVC_OK;
+}
+
+static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_in, float* logits_out, float* latent_out,
+                          int32_t* step_ctr, hipStream_t s) {
+    GVC_REQUIRE(c->p_layers, GVC_ERR_STATE, "persistent decode step: not prepared");
+    PersistArgs A;
+    memset(&A, 0, sizeof(A));
+    A.layers = c->p_layers; A.n_layer = c->dm.n_layer; A.d = c->dm.d_model; A.n_head = c->dm.n_head; A.head_dim = c->hd;
+    A.vocab = c->dm.vocab; A.max_seq = c->dm.max_seq; A.max_mel_pos = c->dm.max_mel_pos;
+    A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.lnf_w = c->lnf_w; A.lnf_b = c->lnf_b; A.fn_w = c->fn_w; A.fn_b = c->fn_b;
+    A.head_w = c->head_w; A.head_b = c->head_b; A.slots = slots; A.tok_in = tok_in; A.st = c->st;
+    A.logits_out = logits_out; A.latent_out = latent_out; A.step_ctr = step_ctr; A.advance = 1;
+    A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr;
+    A.dbg = c->p_dbg;
+    const int nd = c->dm.d_model / 256;
+    if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
+    else if (nd == 2) hipLaunchKernelGGL((k_decode_persist<2>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
+    else hipLaunchKernelGGL((k_decode_persist<1>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
 static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
                         float* latent_out, int32_t* step_ctr, hipStream_t s, bool fused = false) {
     const int d = c->dm.d_model;
@@ -742,8 +825,9 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
 
 static int check_ready(gvc_gpt* c) {
     GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
-    GVC_REQUIRE(!c->seam_err_host || *(volatile int*)c->seam_err_host == 0, GVC_ERR_HIP,
-                "an in-kernel exchange of a fused decode launch timed out (were all its workgroups resident?); unset GVC_FUSE_MLP");
+    GVC_REQUIRE(!c->seam_err_host || *(volatile int*)c->seam_err_host == 0, GVC_ERR_STATE,
+                "an in-kernel hand-off of the one-launch decode step timed out (code %d: were all 256 workgroups resident?); "
+                "the context must be re-created, or run with GVC_PERSIST=0", *(volatile int*)c->seam_err_host);
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
                 gvc_gpt_missing_weights(c));
     return GVC_OK;
@@ -755,6 +839,10 @@ extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, 
     if (rc) return rc;
     GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "decode_step: B=%d outside [1,%d]", B, c->dm.max_slots);
     hipStream_t s = (hipStream_t)sv;
+    if (persist_ok(c, B)) {
+        if ((rc = persist_prepare(c))) return rc;
+        return launch_persist(c, slots, tok_in, logits_out, latent_out, nullptr, s);
+    }
     if (rows_decode_ok(c, B)) return decode_rows(c, slots, B, tok_in, logits_out, latent_out, nullptr, s);
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
@@ -1017,7 +1105,9 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) 
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     if (pf) c->prog_active = c->prog;        // every launch of the step bumps the progress counter
     rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
-    if (rc == GVC_OK && rows_decode_ok(c, B))
+    if (rc == GVC_OK && persist_ok(c, B))
+        rc = launch_persist(c, c->gen_call->slots, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
+    else if (rc == GVC_OK && rows_decode_ok(c, B))
         rc = decode_rows(c, c->gen_call->slots, B, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
     else
     for (int g = 0; g < B && rc == GVC_OK; g += 8) {
@@ -1062,7 +1152,8 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     GVC_LAUNCH_CHECK();
     // ids_stride bounds the cached positions of this run (prefix + 1 + every step the caller will ask for)
     const bool fused = fused_ok(c, B, ids_stride);
-    const int key = B * 2 + (fused ? 1 : 0);          // (rows mode is a pure function of B: same key)
+    const int key = B * 2 + (fused ? 1 : 0);          // (rows mode and the one-launch step are pure functions of B: same key)
+    if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;
@@ -1150,6 +1241,12 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
 
 // debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {
+    if (c && c->p_dbg && max_launches < 0) {     // stamps of the last one-launch decode step: [(layer * 5 + phase) * 2 + {input ready, output published}]
+        (void)hipDeviceSynchronize();
+        const int n = 2 * (5 * c->dm.n_layer + 8);
+        (void)hipMemcpy(host_out, c->p_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        return n;
+    }
     if (!c || !c->dbg) return 0;
     (void)hipDeviceSynchronize();
     const int n = c->dbg_n < max_launches ? c->dbg_n : max_launches;

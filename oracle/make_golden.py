@@ -311,6 +311,27 @@ def make_hubert(seed=17):
     print("hubert:", {k: v.shape for k, v in out.items() if "feat" in str(k)})
 
 
+@torch.inference_mode()
+def make_handle_chunks(seed=19):
+    """reference inference/inference_utils.py:4-21 (imports with torch only): a streamed sequence of vocoder outputs through
+    the reference's own handle_chunks -- first chunk (no overlap yet), regular cross-fades, a short last group (3 tokens),
+    the `overlap_len > len(wav_chunk)` branch (a 1-token group: 1024 samples), and a chunk after that branch (overlap None)."""
+    sys.path.insert(0, "/root/reference")
+    from inference.inference_utils import handle_chunks as ref_handle_chunks
+    lens = [8192, 8192, 3072, 8192, 1024, 8192, 2048]
+    out = dict(seed=seed, lens=np.array(lens))
+    prev, ov = None, None
+    for i, n in enumerate(lens):
+        wav = synth.uniform(seed, f"chunk{i}", (n,), 0.5)
+        chunk, prev, ov = ref_handle_chunks(wav.clone(), prev, ov, 1024)
+        out[f"chunk{i}"] = chunk.numpy().copy()
+        out[f"has_overlap{i}"] = np.array(ov is not None)
+        if ov is not None:
+            out[f"overlap{i}"] = ov.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "handle_chunks.npz"), **out)
+    print("handle_chunks:", [out[f"chunk{i}"].shape[0] for i in range(len(lens))])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -341,6 +362,8 @@ def main():
         make_hifigan()
     if want("hubert"):
         make_hubert()
+    if want("chunks"):
+        make_handle_chunks()
 
 
 if __name__ == "__main__":

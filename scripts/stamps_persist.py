@@ -1,0 +1,34 @@
+"""Phase timeline of the one-launch decode step (GVC_PERSIST_STAMPS=1): workgroup 0's wall-clock stamps."""
+import os, sys, ctypes as C
+os.environ["GVC_PERSIST_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from genvc_amd import config as gcfg, synth, _lib
+from genvc_amd.engine import GptEngine
+
+Tc = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+dims = gcfg.gpt_dims(gcfg.DEFAULT_MODEL_ARGS)
+w = synth.make_weights(1, synth.gpt_weight_spec(dims), device="cuda")
+eng = GptEngine(dims, max_slots=8, max_rows=4096); eng.bind(w)
+dev = "cuda"
+cond = synth.uniform(1, "c", (1, 32, 1024), 1.0).to(dev)
+codes = synth.integers(1, "k", (1, Tc), 256).to(dev).int()
+slots = torch.arange(1, device=dev, dtype=torch.int32)
+eng.prefill(slots, eng.prefix_embeddings(cond, codes), want_outputs=False)
+tok = torch.zeros(1, device=dev, dtype=torch.int32); lg = torch.empty(1, 1026, device=dev); lt = torch.empty(1, 1024, device=dev)
+L = _lib.lib(); L.gvc_gpt_debug_stamps.restype = C.c_int; L.gvc_gpt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+for _ in range(4): eng.decode_step(slots, tok, lg, lt)
+nl = dims["n_layer"]
+hb = np.zeros(2 * (5 * nl + 8), dtype=np.uint64)
+n = L.gvc_gpt_debug_stamps(eng._h, hb.ctypes.data_as(C.c_void_p), -1)
+t0 = int(hb[2 * (5 * nl + 2)])
+us = lambda v: (int(v) - t0) / 100.0
+names = ["A qkv", "B attn", "C proj", "D fc", "E mlp"]
+for l in list(range(3)) + [nl - 1]:
+    print(f"layer {l}: " + "  ".join(f"{names[p]} in {us(hb[(l*5+p)*2]):7.2f} out {us(hb[(l*5+p)*2+1]):7.2f}" for p in range(5)))
+print(f"head in {us(hb[(nl*5)*2]):.2f} out {us(hb[(nl*5)*2+1]):.2f}")
+d = np.array([[us(hb[(l*5+p)*2+k]) for p in range(5) for k in range(2)] for l in range(1, nl)])
+per = np.diff(np.concatenate([d[:-1, -1:], d[1:, :]], axis=1), axis=1).mean(axis=0) if nl > 2 else None
+if per is not None:
+    print("mean us per stage (layers 2..): " + "  ".join(f"{names[i//2]}{' wait' if i%2==0 else ' work'} {per[i]:.2f}" for i in range(10)))
+    print(f"mean per layer {np.diff(d[:, -1]).mean():.2f} us")

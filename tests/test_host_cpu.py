@@ -107,6 +107,20 @@ def test_harness_segmentation_and_chunks_match_oracle():
     assert c3.shape[0] == 1024 and ov3 is None
 
 
+def test_handle_chunks_matches_reference_fixture(gold):
+    """genvc_amd's handle_chunks against outputs of the reference's own function (tests/golden/handle_chunks.npz)"""
+    from genvc_amd.inference.inference_utils import handle_chunks
+    g = gold("handle_chunks")
+    prev, ov = None, None
+    for i, n in enumerate(g["lens"]):
+        wav = synth.uniform(int(g["seed"]), f"chunk{i}", (int(n),), 0.5)
+        chunk, prev, ov = handle_chunks(wav.clone(), prev, ov, 1024)
+        np.testing.assert_allclose(chunk.numpy(), g[f"chunk{i}"], rtol=0, atol=1e-7)
+        assert (ov is not None) == bool(g[f"has_overlap{i}"])
+        if ov is not None:
+            np.testing.assert_array_equal(ov.numpy(), g[f"overlap{i}"])
+
+
 def test_stop_len_rule():
     from genvc_amd.layers.gpt import GPT
     g = GPT(layers=1, model_dim=256, heads=4)

@@ -137,6 +137,20 @@ def test_segmentation_and_chunks():
     assert abs(float(c2[0]) - float(ov[0])) < 1e-6                            # fade starts at the old tail
 
 
+def test_handle_chunks_vs_reference(gold):
+    """the restated cross-fade against the reference's own handle_chunks (oracle/make_golden.py:make_handle_chunks):
+    first chunk, cross-fades, a short group, the 1-token raw-tail branch and the un-faded chunk that follows it"""
+    g = gold("handle_chunks")
+    ov = None
+    for i, n in enumerate(g["lens"]):
+        wav = synth.uniform(int(g["seed"]), f"chunk{i}", (int(n),), 0.5)
+        chunk, ov = O.handle_chunks(wav, ov)
+        np.testing.assert_allclose(chunk.numpy(), g[f"chunk{i}"], rtol=0, atol=1e-7)
+        assert (ov is not None) == bool(g[f"has_overlap{i}"])
+        if ov is not None:
+            np.testing.assert_array_equal(ov.numpy(), g[f"overlap{i}"])
+
+
 def test_hifigan_vs_reference(gold):
     g = gold("hifigan")
     seed = int(g["seed"])
