@@ -251,7 +251,7 @@ struct gvc_gpt {
     pu64* p_gran = nullptr;           // granule buffers of the in-kernel hand-offs
     unsigned* p_epoch = nullptr;      // [0] step epoch, [1] arrival counter
     unsigned long long* p_dbg = nullptr;   // GVC_PERSIST_STAMPS: wall-clock stamps of workgroup 0
-    int p_ring_slots = 0, p_ascr = 0;
+    int p_ring_slots = 0, p_ascr = 0, p_hvec = 0;
     size_t p_lds = 0;
 };
 
@@ -598,6 +598,7 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     A.mel_pos_tab = c->mel_pos;
     A.prog = c->prog_active;
     A.kv_bf16 = c->kv_bf16;
+    A.err = c->seam_err_dev;
     return A;
 }
 
@@ -667,17 +668,19 @@ static int persist_prepare(gvc_gpt* c) {
         p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b; p.fc_w = ly.fc_w; p.fc_b = ly.fc_b; p.p2_w = ly.p2_w; p.p2_b = ly.p2_b;
         p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
     }
-    const size_t ngran = (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + d + 4 * d + d;
+    const size_t ngran = persist_granules(d, H);
     GVC_CHECK_HIP(hipMalloc((void**)&c->p_gran, ngran * sizeof(pu64)));
     GVC_CHECK_HIP(hipMemset(c->p_gran, 0, ngran * sizeof(pu64)));
     GVC_CHECK_HIP(hipMalloc((void**)&c->p_epoch, 4 * sizeof(unsigned)));
     GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned)));
     if (getenv("GVC_PERSIST_STAMPS")) {
-        GVC_CHECK_HIP(hipMalloc((void**)&c->p_dbg, (size_t)2 * (5 * L + 8) * sizeof(unsigned long long)));
-        GVC_CHECK_HIP(hipMemset(c->p_dbg, 0, (size_t)2 * (5 * L + 8) * sizeof(unsigned long long)));
+        GVC_CHECK_HIP(hipMalloc((void**)&c->p_dbg, (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long)));
+        GVC_CHECK_HIP(hipMemset(c->p_dbg, 0, (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long)));
     }
-    c->p_ascr = 3 * c->hd + 1024 + 2 * kPCW * (256 / c->hd);
-    const size_t other = ((size_t)4 * d + d + c->p_ascr) * sizeof(float) + 64;
+    const int ng_hd = kPCW * 256;                       // lane-group states of the attention phase: [kPCW * 64 / (hd / 4)][hd]
+    c->p_hvec = 4 * d > d + ng_hd ? 4 * d : d + ng_hd;
+    c->p_ascr = 3 * c->hd + 64;
+    const size_t other = ((size_t)c->p_hvec + d + c->p_ascr) * sizeof(float) + kCtlWords * sizeof(unsigned);
     c->p_ring_slots = 8;
     while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > 160 * 1024) c->p_ring_slots >>= 1;
     c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
@@ -700,7 +703,7 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.lnf_w = c->lnf_w; A.lnf_b = c->lnf_b; A.fn_w = c->fn_w; A.fn_b = c->fn_b;
     A.head_w = c->head_w; A.head_b = c->head_b; A.slots = slots; A.tok_in = tok_in; A.st = c->st;
     A.logits_out = logits_out; A.latent_out = latent_out; A.step_ctr = step_ctr; A.advance = 1;
-    A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr;
+    A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr; A.hvec_floats = c->p_hvec;
     A.dbg = c->p_dbg;
     const int nd = c->dm.d_model / 256;
     if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
@@ -825,9 +828,13 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
 
 static int check_ready(gvc_gpt* c) {
     GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
-    GVC_REQUIRE(!c->seam_err_host || *(volatile int*)c->seam_err_host == 0, GVC_ERR_STATE,
+    const int dev_err = c->seam_err_host ? *(volatile int*)c->seam_err_host : 0;
+    GVC_REQUIRE(dev_err != 950 && dev_err != 951, GVC_ERR_STATE,
+                "a decode step ran with a full %s (max_seq %d, max_mel_pos %d): its position was not advanced; reset the slot",
+                dev_err == 950 ? "KV cache" : "mel position table", c->dm.max_seq, c->dm.max_mel_pos);
+    GVC_REQUIRE(dev_err == 0, GVC_ERR_STATE,
                 "an in-kernel hand-off of the one-launch decode step timed out (code %d: were all 256 workgroups resident?); "
-                "the context must be re-created, or run with GVC_PERSIST=0", *(volatile int*)c->seam_err_host);
+                "the context must be re-created, or run with GVC_PERSIST=0", dev_err);
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
                 gvc_gpt_missing_weights(c));
     return GVC_OK;
@@ -855,6 +862,7 @@ extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, 
 
 extern "C" int gvc_gpt_reset_slots(gvc_gpt* c, const int32_t* slots, int32_t B, gvc_stream sv) {
     GVC_REQUIRE(c && slots && B >= 1, GVC_ERR_ARG, "reset_slots: bad argument");
+    if (c->seam_err_host && (*c->seam_err_host == 950 || *c->seam_err_host == 951)) *c->seam_err_host = 0;     // overflow acknowledged
     hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)sv, c->st, slots, B, 0, 0);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
@@ -1132,11 +1140,15 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) 
 
 extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                                 int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
-                                int32_t n_steps, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
+                                int32_t n_steps, int32_t max_keys, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
                                 int32_t lat_stride, gvc_stream sv) {
     int rc = check_ready(c);
     if (rc) return rc;
-    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && p && n_steps >= 0, GVC_ERR_ARG, "generate: bad argument");
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && p && n_steps >= 0 && max_keys >= 0, GVC_ERR_ARG, "generate: bad argument");
+    // cached positions of the longest stream once this call has run: the caller's bound, else the whole ids row
+    const int key_bound = max_keys > 0 ? max_keys : ids_stride;
+    GVC_REQUIRE(max_keys == 0 || max_keys < c->dm.max_seq, GVC_ERR_STATE,
+                "generate: %d cached positions would overflow the KV cache (max_seq %d)", max_keys, c->dm.max_seq);
     GVC_REQUIRE(p->vocab == c->dm.vocab, GVC_ERR_ARG, "generate: vocab mismatch");
     hipStream_t s = (hipStream_t)sv;
     SampleCall sc;
@@ -1150,8 +1162,7 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 0);
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 0);
     GVC_LAUNCH_CHECK();
-    // ids_stride bounds the cached positions of this run (prefix + 1 + every step the caller will ask for)
-    const bool fused = fused_ok(c, B, ids_stride);
+    const bool fused = fused_ok(c, B, key_bound);
     const int key = B * 2 + (fused ? 1 : 0);          // (rows mode and the one-launch step are pure functions of B: same key)
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     auto it = c->graphs.find(key);
@@ -1196,9 +1207,12 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     // which 0..5: that class alone; 6: the whole step; 16 + X: the whole step WITHOUT class X (in-situ cost of X =
     // (whole - without) / launches: the class then runs behind its real predecessor, whose output it has to fetch from
     // the other XCDs, instead of re-reading its own stale inputs from L2)
-    const bool whole = which == 6 || (which >= 16 && which <= 21);
+    const bool whole = which == 6 || which == 7 || (which >= 16 && which <= 21);
     GVC_REQUIRE(((which >= 0 && which <= 5) || whole) && B >= 1 && B <= 8 && n_steps >= 1 && avg_us, GVC_ERR_ARG,
                 "time_kernel: bad argument");
+    const bool one_launch = which == 7;
+    GVC_REQUIRE(!one_launch || persist_ok(c, B), GVC_ERR_UNSUPPORTED, "time_kernel: the one-launch decode step does not serve this context");
+    if (one_launch && (rc = persist_prepare(c))) return rc;
     hipStream_t s = (hipStream_t)sv;
     hipEvent_t e0, e1;
     GVC_CHECK_HIP(hipEventCreate(&e0));
@@ -1212,7 +1226,8 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-        rc = decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, c->cap_stream, fused);
+        rc = one_launch ? launch_persist(c, slots, tok_in, c->logits, c->latent, nullptr, c->cap_stream)
+                        : decode_group(c, slots, B, 0, tok_in, c->logits, c->latent, nullptr, c->cap_stream, fused);
         e = hipStreamEndCapture(c->cap_stream, &graph);
     }
     c->prof_only = -1;
@@ -1241,9 +1256,9 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
 
 // debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {
-    if (c && c->p_dbg && max_launches < 0) {     // stamps of the last one-launch decode step: [(layer * 5 + phase) * 2 + {input ready, output published}]
+    if (c && c->p_dbg && max_launches < 0) {     // stamps of the last one-launch decode step (layout: persist_kernel.h)
         (void)hipDeviceSynchronize();
-        const int n = 2 * (5 * c->dm.n_layer + 8);
+        const int n = 20 * (c->dm.n_layer + 2) + 2 * 5 * kPG;
         (void)hipMemcpy(host_out, c->p_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         return n;
     }

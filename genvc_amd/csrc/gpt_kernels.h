@@ -64,6 +64,7 @@ struct GemvArgs {
     // fused attention path (k_attn_proj): PRO_LN_SUM builds x' = x + pbias + sum_h part2[b][h] and stores it to x2;
     // EPI_RESID then reads its residual from xres (= x2) instead of x
     const float* part2; const float* pbias; float* x2; const float* xres;
+    int* err;                                   // device-visible host word: set when a slot's KV cache is full (EPI_LOGITS)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -438,8 +439,11 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
         // the slot's cache grew by one position; the last cache row is re-used once the slot is full
         if (A.advance && blockIdx.x == 0 && threadIdx.x < A.B) {
             const int slot = A.slots[threadIdx.x];
+            // a full cache: the position is not advanced (no write past the slot) and the host is told (GVC_ERR_STATE on its next call)
             if (A.st.seq_len[slot] < A.max_seq - 1) A.st.seq_len[slot] += 1;
+            else if (A.err) *A.err = 950;
             if (A.st.mel_pos[slot] < A.max_mel_pos - 1) A.st.mel_pos[slot] += 1;
+            else if (A.err) *A.err = 951;
         }
         if (A.step_ctr && blockIdx.x == 0 && threadIdx.x == 0) *A.step_ctr += 1;
     }

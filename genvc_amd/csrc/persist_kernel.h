@@ -8,13 +8,15 @@
 //   * a LOADER wave per workgroup streams that workgroup's weight rows (contiguous in the row-per-output layout) into
 //     an LDS ring with LDS-DMA (global_load_lds, non-temporal), at most two 16 KiB fills in flight, up to 8 fills
 //     (~1.5 phases) ahead of the consumers: the HBM stream keeps running across the dependency seams;
-//   * four CONSUMER waves gather the phase input, do the LayerNorm / attention / dot products out of LDS and publish
+//   * eight CONSUMER waves gather the phase input, do the LayerNorm / attention / dot products out of LDS and publish
 //     the phase output.  Consumer waves never have a weight load outstanding (vmcnt retires in order per wave), so
-//     they can poll;
+//     they can poll.  A single wave retires an instruction every ~5-10 ns, so the work of a phase is spread over
+//     all eight waves (rows, or K-halves of a row whose two partial sums are added by the NEXT phase's gather);
 //   * a seam (all-to-all hand-off of a phase output) is a sweep over 8-byte {value, tag} granules: every output
 //     element is written by ONE write-through (sc1) store and polled with sc1 loads until its tag is the expected one.
-//     The tag encodes (step epoch, layer, phase); nothing is zeroed between steps, the epoch lives in device memory and
-//     is bumped by the last workgroup to finish the step.
+//     A sweep first polls one sentinel granule per lane (1/4 .. 1/8 of the traffic and of the instructions of a full
+//     sweep) and reads the rest when the sentinels have arrived.  The tag encodes (step epoch, layer, phase); nothing is
+//     zeroed between steps, the epoch lives in device memory and is bumped by the last workgroup to finish the step.
 // Per layer: A [LN1, c_attn] -> B [attention, split over <= 8 key chunks per head, a few workgroups] ->
 //            C [merge of the chunk partials, attn c_proj, residual] -> D [LN2, c_fc, gelu_new] -> E [mlp c_proj, residual];
 // then the double-LayerNorm head.  Every spin is bounded: on a timeout the workgroup sets *err, and the host raises
@@ -25,12 +27,14 @@
 namespace gvc {
 
 constexpr int kPG = 256;            // workgroups: one per CU, all co-resident
-constexpr int kPCW = 4;             // consumer waves per workgroup (wave kPCW is the loader)
+constexpr int kPCW = 8;             // consumer waves per workgroup (wave kPCW is the loader)
 constexpr int kPThreads = (kPCW + 1) * 64;
 constexpr int kPSlot = 16384;       // bytes per ring slot = one LDS-DMA fill (16 x 1 KiB wave-instructions)
 constexpr int kPMaxChunks = 8;      // key chunks per head
-constexpr int kPU = 8;              // keys per lane group held in registers per pass
+constexpr int kPU = 4;              // keys per lane group held in registers per pass
 constexpr unsigned kPSpinLimit = 400000;
+// LDS control words
+constexpr int kCtlFilled = 0, kCtlDone = 1, kCtlArrive = 1 + kPCW, kCtlAbort = 2 + kPCW, kCtlWords = 16;
 
 typedef unsigned long long pu64;
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
@@ -52,17 +56,20 @@ struct PersistArgs {
     float* latent_out;              // [d]
     int32_t* step_ctr;              // nullable
     int advance;
-    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[d] | HH[4d] | X1[d]
+    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[2][d] | HH[4d] | X1[2][d]
     unsigned* epoch;                // [0] step epoch, [1] arrival counter of the running step
     int* err;                       // device-visible host word: != 0 after a timeout
     int ring_slots;                 // power of two
-    int ascr_floats;
-    unsigned long long* dbg;        // nullable: wall-clock stamps of workgroup 0, [phase][2]
+    int hvec_floats, ascr_floats;
+    unsigned long long* dbg;        // nullable: wall-clock stamps
 };
+
+// granules of the hand-off buffers (host: allocation size)
+static inline size_t persist_granules(int d, int H) { return (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + 2 * d + 4 * d + 2 * d; }
 
 struct PCtx {
     int lane, wave, wg;
-    unsigned* ctl;                  // LDS: [0] filled, [1..4] done per consumer wave, [5] arrive, [6] abort
+    unsigned* ctl;                  // LDS control words (kCtl*)
     int* err;
     unsigned bar_target;
     unsigned filled_seen;
@@ -78,13 +85,14 @@ __device__ __forceinline__ void lds_st(unsigned* p, unsigned v) {
 
 // one failed poll: back off; gives up (and flags the whole workgroup) after ~0.2 s
 __device__ __forceinline__ bool spin_fail(PCtx& c, unsigned& spins, int code, int sleep) {
-    if (sleep == 1) __builtin_amdgcn_s_sleep(1);
-    else __builtin_amdgcn_s_sleep(4);
+    if (sleep == 0) __builtin_amdgcn_s_sleep(0);
+    else if (sleep == 1) __builtin_amdgcn_s_sleep(1);
+    else __builtin_amdgcn_s_sleep(3);
     ++spins;
-    if ((spins & 63u) == 0u && lds_ld(c.ctl + 6)) { c.dead = true; return true; }
+    if ((spins & 63u) == 0u && lds_ld(c.ctl + kCtlAbort)) { c.dead = true; return true; }
     if (spins > kPSpinLimit) {
         c.dead = true;
-        lds_st(c.ctl + 6, 1u);
+        lds_st(c.ctl + kCtlAbort, 1u);
         if (c.lane == 0) __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return true;
     }
@@ -95,10 +103,10 @@ __device__ __forceinline__ bool spin_fail(PCtx& c, unsigned& spins, int code, in
 __device__ __forceinline__ void cbar(PCtx& c) {
     c.bar_target += kPCW;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (c.lane == 0) __hip_atomic_fetch_add(c.ctl + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (c.lane == 0) __hip_atomic_fetch_add(c.ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned spins = 0;
-    while (!c.dead && lds_ld(c.ctl + 5) < c.bar_target)
-        if (spin_fail(c, spins, 900, 1)) break;
+    while (!c.dead && lds_ld(c.ctl + kCtlArrive) < c.bar_target)
+        if (spin_fail(c, spins, 900, 0)) break;
     asm volatile("" ::: "memory");
 }
 
@@ -106,11 +114,15 @@ __device__ __forceinline__ void wait_fill(PCtx& c, unsigned seq) {
     if (c.dead || c.filled_seen > seq) return;
     unsigned spins = 0;
     while (true) {
-        const unsigned f = lds_ld(c.ctl);
+        const unsigned f = lds_ld(c.ctl + kCtlFilled);
         if (f > seq) { c.filled_seen = f; break; }
         if (spin_fail(c, spins, 901, 1)) break;
     }
     asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
 // one {value, tag} granule = ONE 8-byte write-through store (index = granule number inside the allocation)
@@ -120,74 +132,71 @@ __device__ __forceinline__ void publish(__amdgpu_buffer_rsrc_t rs, int index, un
     __builtin_amdgcn_raw_buffer_store_b64(g, rs, index * 8, 0, 16);
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-
-// The consumer waves sweep n consecutive granules (starting `base` bytes into the granule allocation) until every tag
-// matches; values land in dst[t].  Load j of a lane covers item (j * kPCW + wave) * 64 + lane; only loads that still
-// hold an old tag are re-issued.  Buffer addressing: ONE per-lane offset register serves every load of the sweep.
-template <int MAXL>
+// Sweep of a phase input by the consumer waves.  The input has NP planes of n granules (a K-split producer publishes
+// one partial sum per plane; the value is their sum, plane 0 first); item t of plane p sits at granule base + p * n + t.
+// A lane reads TWO adjacent granules per load (16 bytes): lane (wave, lane) owns items 2 (wave * 64 + lane) + {0, 1} +
+// j * 128 kPCW, j < NJ.  Load (j = 0, last plane) is the sentinel: it alone is polled until its tags arrive, then the
+// other loads are issued (and everything re-issued if a tag is still old).  n is a multiple of 128.
+template <int NJ, int NP>
 __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code) {
-    if (c.dead) return;
-    unsigned pend = 0;
-#pragma unroll
-    for (int j = 0; j < MAXL; ++j)
-        if ((j * kPCW + c.wave) * 64 < n) pend |= 1u << j;
-    const int t0 = c.wave * 64 + c.lane;
-    const int voff = t0 * 8;
-    pu32x2 v[MAXL];
+    if (c.dead || c.wave * 128 >= n) return;         // a wave is all in or all out
+    const int t0 = 2 * (c.wave * 64 + c.lane);
+    const int voff = (base + t0) * 8;
+    constexpr int JT = kPCW * 128;                   // items between loads j and j + 1 of a lane
     unsigned spins = 0;
-    while (pend) {
+    pu32x4 v[NJ][NP];
+    while (true) {
+        v[0][NP - 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (NP - 1) * n * 8, 16);
+        if (__all(v[0][NP - 1].y == tag && v[0][NP - 1].w == tag)) break;
+        if (spin_fail(c, spins, code, 3)) return;
+    }
+    while (true) {
+        unsigned bad = 0;
 #pragma unroll
-        for (int j = 0; j < MAXL; ++j)
-            if (pend & (1u << j)) v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, base + j * (kPCW * 64 * 8), 16);
-        unsigned np = 0;
+        for (int j = 0; j < NJ; ++j) {
+            if (j == 0 || c.wave * 128 + j * JT < n) {
 #pragma unroll
-        for (int j = 0; j < MAXL; ++j) {
-            if (pend & (1u << j)) {
-                const int t = t0 + j * (kPCW * 64);
-                const bool ok = t >= n || v[j].y == tag;
-                if (t < n && ok) dst[t] = __uint_as_float(v[j].x);
-                if (!__all(ok)) np |= 1u << j;
+                for (int p = 0; p < NP; ++p)
+                    if (!(j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
             }
         }
-        pend = np;
-        if (pend && spin_fail(c, spins, code, 4)) break;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j == 0 || c.wave * 128 + j * JT < n) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bad |= (v[j][p].y ^ tag) | (v[j][p].w ^ tag);
+            }
+        }
+        if (!__any(bad != 0u)) break;
+        if (spin_fail(c, spins, code, 3)) return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j == 0 || c.wave * 128 + j * JT < n) {
+            float s0 = __uint_as_float(v[j][0].x), s1 = __uint_as_float(v[j][0].z);
+#pragma unroll
+            for (int p = 1; p < NP; ++p) { s0 += __uint_as_float(v[j][p].x); s1 += __uint_as_float(v[j][p].z); }
+            *reinterpret_cast<float2*>(dst + t0 + j * JT) = make_float2(s0, s1);
+        }
     }
 }
 
-// the same for up to 3 * 64 * kPCW items whose granule index comes from a map (attention: q_h | k_h | v_h slices)
+// up to 3 * 64 items whose granule index comes from a map (attention: q_h | k_h | v_h slices), item j * 64 + lane by
+// wave j (one load per lane)
 template <typename Map>
 __device__ __forceinline__ void gather_mapped(PCtx& c, __amdgpu_buffer_rsrc_t rs, int n, unsigned tag, float* dst, int code, Map map) {
     if (c.dead) return;
-    constexpr int MAXL = 3;
-    unsigned pend = 0;
-#pragma unroll
-    for (int j = 0; j < MAXL; ++j)
-        if ((j * kPCW + c.wave) * 64 < n) pend |= 1u << j;
-    pu32x2 v[MAXL];
     unsigned spins = 0;
-    while (pend) {
-#pragma unroll
-        for (int j = 0; j < MAXL; ++j) {
-            if (pend & (1u << j)) {
-                const int t = (j * kPCW + c.wave) * 64 + c.lane;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b64(rs, map(t < n ? t : 0) * 8, 0, 16);
-            }
+    for (int tw = c.wave * 64; tw < n; tw += kPCW * 64) {      // (wave-uniform trip count)
+        const int t = tw + c.lane;
+        const int off = map(t < n ? t : 0) * 8;
+        pu32x2 v;
+        while (true) {
+            v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16);
+            if (__all(t >= n || v.y == tag)) break;
+            if (spin_fail(c, spins, code, 3)) return;
         }
-        unsigned np = 0;
-#pragma unroll
-        for (int j = 0; j < MAXL; ++j) {
-            if (pend & (1u << j)) {
-                const int t = (j * kPCW + c.wave) * 64 + c.lane;
-                const bool ok = t >= n || v[j].y == tag;
-                if (t < n && ok) dst[t] = __uint_as_float(v[j].x);
-                if (!__all(ok)) np |= 1u << j;
-            }
-        }
-        pend = np;
-        if (pend && spin_fail(c, spins, code, 4)) break;
+        if (t < n) dst[t] = __uint_as_float(v.x);
     }
 }
 
@@ -197,21 +206,21 @@ __device__ __forceinline__ void vec_from_lds(const float* src, int lane, float4 
     for (int i = 0; i < VN; ++i) v[i] = *reinterpret_cast<const float4*>(src + i * 256 + lane * 4);
 }
 
-// dot product of one weight row (VN KiB in the ring, starting at byte `off` of the segment whose first fill is s0)
+// per-lane partial dot product of VN KiB of one weight row (in the ring from byte `off` of the segment whose first fill is
+// s0; the caller has waited for the fills) with vec
 template <int VN>
-__device__ __forceinline__ float row_dot(PCtx& c, const char* ring, unsigned rmask, unsigned s0, unsigned off,
-                                         const float4 (&vec)[VN]) {
-    wait_fill(c, s0 + ((off + VN * 1024u - 1u) >> 14));
+__device__ __forceinline__ float row_partial(const char* ring, unsigned rmask, unsigned s0, unsigned off, int lane,
+                                             const float4 (&vec)[VN]) {
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
         const unsigned o = off + j * 1024u;
         const unsigned slot = (s0 + (o >> 14)) & rmask;
-        const float4 w = *reinterpret_cast<const float4*>(ring + slot * kPSlot + (o & 16383u) + c.lane * 16);
+        const float4 w = *reinterpret_cast<const float4*>(ring + slot * kPSlot + (o & 16383u) + lane * 16);
         sx = fmaf(w.x, vec[j].x, sx); sy = fmaf(w.y, vec[j].y, sy);
         sz = fmaf(w.z, vec[j].z, sz); sw = fmaf(w.w, vec[j].w, sw);
     }
-    return wave_sum((sx + sy) + (sz + sw));
+    return (sx + sy) + (sz + sw);
 }
 
 template <int ND>
@@ -224,14 +233,14 @@ __device__ __forceinline__ void layer_norm_regs(float4 (&v)[ND], const float4 (&
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
-        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-        v[i].x = (v[i].x - mean) * rstd * g[i].x + b[i].x; v[i].y = (v[i].y - mean) * rstd * g[i].y + b[i].y;
-        v[i].z = (v[i].z - mean) * rstd * g[i].z + b[i].z; v[i].w = (v[i].w - mean) * rstd * g[i].w + b[i].w;
+        v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
+        v[i].z = v[i].z * rstd * g[i].z + b[i].z; v[i].w = v[i].w * rstd * g[i].w + b[i].w;
     }
 }
 
@@ -250,6 +259,52 @@ __device__ __forceinline__ float group_sum(float v, int lpk) {
     v = row16_sum(v);
     if (lpk == 32) v += __shfl_xor(v, 16);
     return v;
+}
+
+// Phase C input: the <= kPMaxChunks key-chunk partials (o, m, l) of the head that owns flat output dims [e, e + 4).  Polls the
+// {m, l} granules of the LAST chunk (sentinel), then reads every chunk and merges the partial softmax states.  NCT >= nchunks
+// is a compile-time bound (registers are statically indexed); slots past nchunks re-read the last chunk with weight 0.
+template <int NCT>
+__device__ __forceinline__ float4 merge_chunks(PCtx& c, __amdgpu_buffer_rsrc_t grs, int iP, int PS, int D, int nchunks, int e, int h,
+                                               unsigned tg, int code) {
+    pu32x4 oa[NCT], ob[NCT], ml[NCT];
+    unsigned spins = 0;
+    const int ml_last = (iP + (nchunks - 1) * PS + D + 2 * h) * 8;
+    while (true) {
+        ml[0] = __builtin_amdgcn_raw_buffer_load_b128(grs, ml_last, 0, 16);
+        if (__all(ml[0].y == tg && ml[0].w == tg)) break;
+        if (spin_fail(c, spins, code, 3)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    while (true) {
+        unsigned bad = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCT; ++ch) {
+            const int cc = ch < nchunks ? ch : nchunks - 1;
+            const int off = (iP + cc * PS + e) * 8;
+            oa[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
+            ob[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, off + 16, 0, 16);
+            ml[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, (iP + cc * PS + D + 2 * h) * 8, 0, 16);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCT; ++ch)
+            bad |= (oa[ch].y ^ tg) | (oa[ch].w ^ tg) | (ob[ch].y ^ tg) | (ob[ch].w ^ tg) | (ml[ch].y ^ tg) | (ml[ch].w ^ tg);
+        if (!__any(bad != 0u)) break;
+        if (spin_fail(c, spins, code, 3)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int ch = 0; ch < NCT; ++ch) M = fmaxf(M, __uint_as_float(ml[ch].x));
+    float Lt = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ch = 0; ch < NCT; ++ch) {
+        const float wgt = ch < nchunks ? __expf(__uint_as_float(ml[ch].x) - M) : 0.f;
+        Lt += wgt * __uint_as_float(ml[ch].z);
+        o.x = fmaf(wgt, __uint_as_float(oa[ch].x), o.x); o.y = fmaf(wgt, __uint_as_float(oa[ch].z), o.y);
+        o.z = fmaf(wgt, __uint_as_float(ob[ch].x), o.z); o.w = fmaf(wgt, __uint_as_float(ob[ch].z), o.w);
+    }
+    const float inv = 1.0f / Lt;
+    return make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
 }
 
 // ---- loader wave: the workgroup's weight rows, phase after phase, into the ring ---------------------------------
@@ -283,11 +338,13 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
             unsigned spins = 0;
             bool drained = false;
             while (!c.dead) {
-                const unsigned m = min(min(lds_ld(c.ctl + 1), lds_ld(c.ctl + 2)), min(lds_ld(c.ctl + 3), lds_ld(c.ctl + 4)));
+                unsigned m = lds_ld(c.ctl + kCtlDone);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) m = min(m, lds_ld(c.ctl + kCtlDone + w));
                 if (fseq < m + (unsigned)A.ring_slots) break;
                 if (!drained) {      // blocked: whatever was issued is landed and announced before waiting
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lds_st(c.ctl, fseq);
+                    lds_st(c.ctl + kCtlFilled, fseq);
                     drained = true;
                 }
                 if (spin_fail(c, spins, 902, 1)) break;
@@ -303,35 +360,38 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                lds_st(c.ctl, fseq);
+                lds_st(c.ctl + kCtlFilled, fseq);
             } else {
 #pragma unroll 1
                 for (unsigned i = 0; i < n; ++i)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                lds_st(c.ctl, fseq + 1);
+                lds_st(c.ctl + kCtlFilled, fseq + 1);
             }
             ++fseq;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_st(c.ctl, fseq);
+    lds_st(c.ctl + kCtlFilled, fseq);
 }
 
 // ---- decode-step kernel --------------------------------------------------------------------------------------
 template <int ND>      // d_model = 256 * ND
 __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs A) {
     constexpr int D = 256 * ND;
+    constexpr int KSC = ND >= 2 ? 2 : 1;         // K-split of an attn c_proj row over waves (partial sums = planes of X0)
+    constexpr int KSE = 2;                       // K-split of an mlp c_proj row (planes of X1)
+    constexpr int NJX = (D + kPCW * 128 - 1) / (kPCW * 128);        // 16-byte loads per lane and plane in a sweep over a d-vector
     extern __shared__ __attribute__((aligned(16))) float smem[];      // (same declaration as k_gemv's)
     char* ring = reinterpret_cast<char*>(smem);
     float* hvec = reinterpret_cast<float*>(ring + (size_t)A.ring_slots * kPSlot);      // [4D] mlp hidden units
-    float* xvec = hvec + 4 * D;                                                        // [D] phase input (x / x')
-    float* ovec = hvec;                                                                // [D] merged attention output: aliases hvec, which
-                                                                                       // is idle between E of a layer and E of the next
-    float* ascr = xvec + D;                                                            // attention scratch
+    float* ovec = hvec;                          // [D] merged attention output: hvec is idle between E of a layer and E of the next
+    float* o_s = hvec + D;                       // attention lane-group states [NG][hd] (phase B; same idle window)
+    float* xvec = hvec + A.hvec_floats;          // [D] phase input (x / x')
+    float* ascr = xvec + D;                      // attention: q_h | k_h | v_h of this step, then m_s, l_s
     unsigned* ctl = reinterpret_cast<unsigned*>(ascr + A.ascr_floats);
-    if (threadIdx.x < 8) ctl[threadIdx.x] = 0u;
+    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0u;
     __syncthreads();
 
     PCtx c;
@@ -361,15 +421,22 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const float scale = 1.0f / sqrtf((float)hd);
         const int PS = D + 2 * H;                        // granules per key chunk: o[D] | {m, l}[H]
         // granule indices of the five hand-off buffers inside the allocation
-        const int iQ = 0, iP = 3 * D, iX0 = iP + kPMaxChunks * PS, iH = iX0 + D, iX1 = iH + 4 * D;
-        const __amdgpu_buffer_rsrc_t grs = make_rsrc(A.gran, (unsigned)(iX1 + D) * 8u);
+        const int iQ = 0, iP = 3 * D, iX0 = iP + kPMaxChunks * PS, iH = iX0 + 2 * D, iX1 = iH + 4 * D;
+        const __amdgpu_buffer_rsrc_t grs = make_rsrc(A.gran, (unsigned)(iX1 + 2 * D) * 8u);
         const unsigned tbase = ((epoch + 1u) & 0xfffffu) << 12;
         auto tag_of = [&](int l, int p) { return tbase | (unsigned)(l * 8 + p + 1); };
-        const bool stamp = A.dbg && wg == 0 && wave == 0 && lane == 0;
-        auto stamp_at = [&](int l, int p, int k) { if (stamp) A.dbg[(l * 5 + p) * 2 + k] = wall_clock64(); };
+        // stamps (GVC_PERSIST_STAMPS): workgroup 0, every layer: [(l * 5 + p) * 4 + k], k = 0 input ready, 1 output published,
+        // 2 / 3 extra; every workgroup, layer 2: [base2 + (wg * 5 + p) * 2 + k]
+        const bool stamp0 = A.dbg && wave == 0 && lane == 0;
+        const int base2 = 4 * 5 * (A.n_layer + 2);
+        auto stamp_at = [&](int l, int p, int k) {
+            if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 4 + k] = wall_clock64();
+            if (stamp0 && l == 2 && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
+        };
         unsigned fs = 0;                                 // first fill of the current weight segment
         constexpr unsigned nfA = (3 * ND * D * 4 + kPSlot - 1) / kPSlot, nfC = (ND * D * 4 + kPSlot - 1) / kPSlot,
                            nfD = (4 * ND * D * 4 + kPSlot - 1) / kPSlot;
+        auto phase_done = [&]() { if (lane == 0) lds_st(ctl + kCtlDone + wave, fs); };
 
         // ---- x = mel_embedding[tok] + mel_pos_embedding[pos]  (gpt_inference.py:92-96), by every workgroup ----
         if (wave < ND) {
@@ -378,34 +445,40 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             const float4 ev = *reinterpret_cast<const float4*>(e), pv = *reinterpret_cast<const float4*>(p);
             *reinterpret_cast<float4*>(xvec + wave * 256 + lane * 4) = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);
         }
-        float xres = 0.f;                                // residual element wg * ND + wave (waves < ND)
-        if (stamp) A.dbg[2 * (5 * A.n_layer + 2)] = wall_clock64();
+        if (stamp0 && wg == 0) A.dbg[4 * 5 * (A.n_layer + 1)] = wall_clock64();      // kernel entry
 
         for (int l = 0; l < A.n_layer; ++l) {
             const PersistLayer& Ly = A.layers[l];
             // =================== A: LN1 -> c_attn rows -> q | k | v ===================
-            GVC_PHASE_BEGIN();
+            // row (wave + 8 i) of the workgroup's 3 ND rows belongs to wave `wave`
             {
+                GVC_PHASE_BEGIN();
                 float4 g[ND], b[ND], xv[ND];
                 load_gb<ND>(Ly.ln1_w, Ly.ln1_b, lane, g, b);
                 constexpr int RA = 3 * ND, UPW = (RA + kPCW - 1) / kPCW;
-                const int r0 = wave * UPW, nmy = max(0, min(RA, r0 + UPW) - r0);
-                const int row_g = wg * RA + r0 + lane;
+                const int nmy = wave < RA ? (RA - wave + kPCW - 1) / kPCW : 0;
+                const int row_g = wg * RA + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.qkv_b[row_g] : 0.f;
-                if (l > 0) gather<ND>(c, grs, iX1 * 8, D, tag_of(l - 1, 4), xvec, 100 + l);
+                if (l > 0) gather<NJX, KSE>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l);
                 cbar(c);
                 stamp_at(l, 0, 0);
-                vec_from_lds<ND>(xvec, lane, xv);
-                if (l == 0 && wave < ND) xres = xvec[wg * ND + wave];
-                layer_norm_regs<ND>(xv, g, b);
                 float val = 0.f;
+                if (nmy > 0) {
+                    vec_from_lds<ND>(xvec, lane, xv);
+                    layer_norm_regs<ND>(xv, g, b);
+                    stamp_at(l, 0, 2);
+                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> 14));
+                    float part[UPW];
 #pragma unroll
-                for (int i = 0; i < UPW; ++i) {
-                    if (i < nmy) {
-                        const float s = row_dot<ND>(c, ring, rmask, fs, (unsigned)(r0 + i) * D * 4, xv);
+                    for (int i = 0; i < UPW; ++i)
+                        part[i] = i < nmy ? row_partial<ND>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < UPW; ++i) {
+                        const float s = wave_sum(part[i]);
                         if (lane == i) val = s;
                     }
                 }
+                stamp_at(l, 0, 3);
                 if (lane < nmy) {
                     val += bias;
                     publish(grs, iQ + row_g, tag_of(l, 0), val);
@@ -417,12 +490,12 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     }
                 }
                 fs += nfA;
-                if (lane == 0) lds_st(ctl + 1 + wave, fs);
+                phase_done();
                 stamp_at(l, 0, 1);
             }
             // =================== B: attention over one key chunk of one head (a few workgroups) ===================
-            GVC_PHASE_BEGIN();
             if (is_attn) {
+                GVC_PHASE_BEGIN();
                 const int kl = lane / lpk, dl = (lane - kl * lpk) * 4;
                 const int k0 = ac * kc, k1 = min(S, k0 + kc);            // cached keys of this chunk
                 // this head's rows of the layer's K / V cache as buffers: one per-lane offset serves every key of a pass
@@ -477,36 +550,38 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     if (kbase > k0) load_pass(kbase);
                     float s[kPU];
 #pragma unroll
+                    for (int u = 0; u < kPU; ++u) s[u] = dot4(q4, kr[u]);
+#pragma unroll
                     for (int u = 0; u < kPU; ++u) {
                         const int key = kbase + (u * kPCW + wave) * kpw + kl;
-                        const float dsum = group_sum(dot4(q4, kr[u]), lpk);
+                        const float dsum = group_sum(s[u], lpk);
                         s[u] = key < k1 ? dsum * scale : -INFINITY;
                     }
                     fold(s);
                 }
-                if (last_chunk && wave == 0) {           // the key of this step: lane group 0 of wave 0
+                if (last_chunk && wave == kPCW - 1) {    // the key of this step: lane group 0 of the last consumer wave
                     float s[kPU];
 #pragma unroll
                     for (int u = 0; u < kPU; ++u) {
                         s[u] = -INFINITY;
-                        kr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                         vr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    kr[0] = *reinterpret_cast<const float4*>(ascr + hd + dl);
+                    const float4 kn = *reinterpret_cast<const float4*>(ascr + hd + dl);
                     vr[0] = *reinterpret_cast<const float4*>(ascr + 2 * hd + dl);
-                    const float dsum = group_sum(dot4(q4, kr[0]), lpk);
+                    const float dsum = group_sum(dot4(q4, kn), lpk);
                     if (kl == 0) s[0] = dsum * scale;
                     fold(s);
                 }
+                stamp_at(l, 1, 2);
                 // merge the kPCW * kpw lane-group states of the workgroup
                 const int NG = kPCW * kpw;
-                float* o_s = ascr + 3 * hd;              // [NG][hd]
-                float* m_s = o_s + NG * hd;              // [NG]
+                float* m_s = ascr + 3 * hd;              // [NG]
                 float* l_s = m_s + NG;                   // [NG]
                 const int gidx = wave * kpw + kl;
                 if (dl == 0) { m_s[gidx] = m; l_s[gidx] = lsum; }
                 *reinterpret_cast<float4*>(o_s + gidx * hd + dl) = o;
                 cbar(c);
+                stamp_at(l, 1, 3);
                 const int tid = wave * 64 + lane;
                 if (tid < hd) {
                     float M = -INFINITY;
@@ -526,128 +601,107 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 }
                 stamp_at(l, 1, 1);
             }
-            // =================== C: merge chunk partials -> attn c_proj rows -> x' = x + ... ===================
-            GVC_PHASE_BEGIN();
+            // =================== C: merge chunk partials -> attn c_proj (row, K-half) units -> x' = x + ... ===================
             {
-                const float bias = wave < ND ? Ly.proj_b[wg * ND + wave] : 0.f;
+                GVC_PHASE_BEGIN();
+                constexpr int VN = ND / KSC;             // KiB of a row per unit
+                const int crow = wave / KSC, cks = wave - crow * KSC;
+                const bool unit = wave < ND * KSC;
+                const float bias = unit && cks == 0 ? Ly.proj_b[wg * ND + crow] : 0.f;
                 if (wave < ND && !c.dead) {
                     const int e = wave * 256 + lane * 4, h = e / hd;
                     const unsigned tg = tag_of(l, 1);
-                    pu32x4 oa[kPMaxChunks], ob[kPMaxChunks], ml[kPMaxChunks];
-                    unsigned pend = (1u << nchunks) - 1u;
-                    unsigned spins = 0;
-                    while (pend) {
-#pragma unroll
-                        for (int ch = 0; ch < kPMaxChunks; ++ch) {
-                            if (pend & (1u << ch)) {
-                                const int off = (iP + ch * PS + e) * 8;
-                                oa[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
-                                ob[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, off + 16, 0, 16);
-                                ml[ch] = __builtin_amdgcn_raw_buffer_load_b128(grs, (iP + ch * PS + D + 2 * h) * 8, 0, 16);
-                            }
-                        }
-                        unsigned np = 0;
-#pragma unroll
-                        for (int ch = 0; ch < kPMaxChunks; ++ch) {
-                            if (pend & (1u << ch)) {
-                                const bool ok = oa[ch].y == tg && oa[ch].w == tg && ob[ch].y == tg && ob[ch].w == tg &&
-                                                ml[ch].y == tg && ml[ch].w == tg;
-                                if (!__all(ok)) np |= 1u << ch;
-                            }
-                        }
-                        pend = np;
-                        if (pend && spin_fail(c, spins, 300 + l, 4)) break;
-                    }
-                    float M = -INFINITY;
-#pragma unroll
-                    for (int ch = 0; ch < kPMaxChunks; ++ch)
-                        if (ch < nchunks) M = fmaxf(M, __uint_as_float(ml[ch].x));
-                    float Lt = 0.f;
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int ch = 0; ch < kPMaxChunks; ++ch) {
-                        if (ch < nchunks) {
-                            const float wgt = __expf(__uint_as_float(ml[ch].x) - M);
-                            Lt += wgt * __uint_as_float(ml[ch].z);
-                            o.x = fmaf(wgt, __uint_as_float(oa[ch].x), o.x); o.y = fmaf(wgt, __uint_as_float(oa[ch].z), o.y);
-                            o.z = fmaf(wgt, __uint_as_float(ob[ch].x), o.z); o.w = fmaf(wgt, __uint_as_float(ob[ch].z), o.w);
-                        }
-                    }
-                    const float inv = 1.0f / Lt;
-                    *reinterpret_cast<float4*>(ovec + e) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+                    float4 o;
+                    if (nchunks <= 2) o = merge_chunks<2>(c, grs, iP, PS, D, nchunks, e, h, tg, 300 + l);
+                    else if (nchunks <= 4) o = merge_chunks<4>(c, grs, iP, PS, D, nchunks, e, h, tg, 300 + l);
+                    else o = merge_chunks<kPMaxChunks>(c, grs, iP, PS, D, nchunks, e, h, tg, 300 + l);
+                    *reinterpret_cast<float4*>(ovec + e) = o;
                 }
                 cbar(c);
                 stamp_at(l, 2, 0);
-                if (wave < ND) {
-                    float4 ov[ND];
-                    vec_from_lds<ND>(ovec, lane, ov);
-                    const float s = row_dot<ND>(c, ring, rmask, fs, (unsigned)wave * D * 4, ov);
-                    xres = xres + (s + bias);
-                    if (lane == 0) publish(grs, iX0 + wg * ND + wave, tag_of(l, 2), xres);
+                if (unit) {
+                    float4 ov[VN];
+                    vec_from_lds<VN>(ovec + cks * VN * 256, lane, ov);
+                    const unsigned off = (unsigned)crow * D * 4 + (unsigned)cks * VN * 1024u;
+                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> 14));
+                    float s = wave_sum(row_partial<VN>(ring, rmask, fs, off, lane, ov));
+                    if (cks == 0) s = xvec[wg * ND + crow] + (s + bias);       // residual: x of this layer (A's input) is still in xvec
+                    if (lane == 0) publish(grs, iX0 + cks * D + wg * ND + crow, tag_of(l, 2), s);
                 }
                 fs += nfC;
-                if (lane == 0) lds_st(ctl + 1 + wave, fs);
+                phase_done();
                 stamp_at(l, 2, 1);
             }
             // =================== D: LN2 -> c_fc rows -> gelu_new ===================
-            GVC_PHASE_BEGIN();
             {
+                GVC_PHASE_BEGIN();
                 float4 g[ND], b[ND], xv[ND];
                 load_gb<ND>(Ly.ln2_w, Ly.ln2_b, lane, g, b);
-                constexpr int RD = 4 * ND, UPW = RD / kPCW;      // ND rows per wave
-                const int r0 = wave * UPW;
-                const int row_g = wg * RD + r0 + lane;
-                const float bias = lane < UPW ? Ly.fc_b[row_g] : 0.f;
-                gather<ND>(c, grs, iX0 * 8, D, tag_of(l, 2), xvec, 400 + l);
+                constexpr int RD = 4 * ND, UPW = (RD + kPCW - 1) / kPCW;
+                const int nmy = wave < RD ? (RD - wave + kPCW - 1) / kPCW : 0;
+                const int row_g = wg * RD + wave + kPCW * lane;
+                const float bias = lane < nmy ? Ly.fc_b[row_g] : 0.f;
+                gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 cbar(c);
                 stamp_at(l, 3, 0);
-                vec_from_lds<ND>(xvec, lane, xv);
-                layer_norm_regs<ND>(xv, g, b);
                 float val = 0.f;
+                if (nmy > 0) {
+                    vec_from_lds<ND>(xvec, lane, xv);
+                    layer_norm_regs<ND>(xv, g, b);
+                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> 14));
+                    float part[UPW];
 #pragma unroll
-                for (int i = 0; i < UPW; ++i) {
-                    const float s = row_dot<ND>(c, ring, rmask, fs, (unsigned)(r0 + i) * D * 4, xv);
-                    if (lane == i) val = s;
+                    for (int i = 0; i < UPW; ++i)
+                        part[i] = i < nmy ? row_partial<ND>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
+#pragma unroll
+                    for (int i = 0; i < UPW; ++i) {
+                        const float s = wave_sum(part[i]);
+                        if (lane == i) val = s;
+                    }
                 }
-                if (lane < UPW) publish(grs, iH + row_g, tag_of(l, 3), gelu_new(val + bias));
+                if (lane < nmy) publish(grs, iH + row_g, tag_of(l, 3), gelu_new(val + bias));
                 fs += nfD;
-                if (lane == 0) lds_st(ctl + 1 + wave, fs);
+                phase_done();
                 stamp_at(l, 3, 1);
             }
-            // =================== E: mlp c_proj rows -> x = x' + ... ===================
-            GVC_PHASE_BEGIN();
+            // =================== E: mlp c_proj (row, K-half) units -> x = x' + ... ===================
             {
-                const float bias = wave < ND ? Ly.p2_b[wg * ND + wave] : 0.f;
-                gather<4 * ND>(c, grs, iH * 8, 4 * D, tag_of(l, 3), hvec, 500 + l);
+                GVC_PHASE_BEGIN();
+                constexpr int VN = 4 * ND / KSE;         // KiB of a row per unit
+                const int erow = wave / KSE, eks = wave - erow * KSE;
+                const bool unit = wave < ND * KSE;
+                const float bias = unit && eks == 0 ? Ly.p2_b[wg * ND + erow] : 0.f;
+                gather<(4 * D + kPCW * 128 - 1) / (kPCW * 128), 1>(c, grs, iH, 4 * D, tag_of(l, 3), hvec, 500 + l);
                 cbar(c);
                 stamp_at(l, 4, 0);
-                if (wave < ND) {
-                    float4 hv[4 * ND];
-                    vec_from_lds<4 * ND>(hvec, lane, hv);
-                    const float s = row_dot<4 * ND>(c, ring, rmask, fs, (unsigned)wave * 4 * D * 4, hv);
-                    xres = xres + (s + bias);
-                    if (lane == 0) publish(grs, iX1 + wg * ND + wave, tag_of(l, 4), xres);
+                if (unit) {
+                    float4 hv[VN];
+                    vec_from_lds<VN>(hvec + eks * VN * 256, lane, hv);
+                    const unsigned off = (unsigned)erow * 4 * D * 4 + (unsigned)eks * VN * 1024u;
+                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> 14));
+                    float s = wave_sum(row_partial<VN>(ring, rmask, fs, off, lane, hv));
+                    if (eks == 0) s = xvec[wg * ND + erow] + (s + bias);       // residual: x' (D's input) is still in xvec
+                    if (lane == 0) publish(grs, iX1 + eks * D + wg * ND + erow, tag_of(l, 4), s);
                 }
                 fs += nfD;
-                if (lane == 0) lds_st(ctl + 1 + wave, fs);
+                phase_done();
                 stamp_at(l, 4, 1);
             }
         }
         // =================== head: ln_f -> final_norm -> latent -> mel_head rows ===================
-        GVC_PHASE_BEGIN();
         {
+            GVC_PHASE_BEGIN();
             const int L = A.n_layer;
             float4 g[ND], b[ND], g2[ND], b2[ND], xv[ND];
             load_gb<ND>(A.lnf_w, A.lnf_b, lane, g, b);
             load_gb<ND>(A.fn_w, A.fn_b, lane, g2, b2);
             const int rm = A.vocab / kPG, rem = A.vocab - rm * kPG;
-            const int upw = (rm + kPCW - 1) / kPCW;
-            const int r0 = wave * upw, nmy = max(0, min(rm, r0 + upw) - r0);
-            const int row_g = wg * rm + r0 + lane;
+            const int nmy = wave < rm ? (rm - wave + kPCW - 1) / kPCW : 0;
+            const int row_g = wg * rm + wave + kPCW * lane;
             const float bias = lane < nmy ? A.head_b[row_g] : 0.f;
-            const bool tail = wave == 0 && wg < rem;
+            const bool tail = wave == kPCW - 1 && wg < rem;
             const float tbias = tail ? A.head_b[rm * kPG + wg] : 0.f;
-            gather<ND>(c, grs, iX1 * 8, D, tag_of(L - 1, 4), xvec, 600);
+            gather<NJX, KSE>(c, grs, iX1, D, tag_of(L - 1, 4), xvec, 600);
             cbar(c);
             stamp_at(L, 0, 0);
             vec_from_lds<ND>(xvec, lane, xv);
@@ -659,28 +713,33 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             }
             float val = 0.f;
             for (int i = 0; i < nmy; ++i) {
-                const float s = row_dot<ND>(c, ring, rmask, fs, (unsigned)(r0 + i) * D * 4, xv);
+                const unsigned off = (unsigned)(wave + kPCW * i) * D * 4;
+                wait_fill(c, fs + ((off + D * 4 - 1) >> 14));
+                const float s = wave_sum(row_partial<ND>(ring, rmask, fs, off, lane, xv));
                 if (lane == i) val = s;
             }
             if (lane < nmy) A.logits_out[row_g] = val + bias;
             if (rm > 0) fs += (rm * D * 4 + kPSlot - 1) / kPSlot;
             if (tail) {
-                const float s = row_dot<ND>(c, ring, rmask, fs, 0u, xv);
+                wait_fill(c, fs);
+                const float s = wave_sum(row_partial<ND>(ring, rmask, fs, 0u, lane, xv));
                 if (lane == 0) A.logits_out[rm * kPG + wg] = s + tbias;
             }
             if (wg < rem) fs += (D * 4 + kPSlot - 1) / kPSlot;
-            if (lane == 0) lds_st(ctl + 1 + wave, fs);
+            phase_done();
             stamp_at(L, 0, 1);
             if (wg == 0 && wave == 0 && lane == 0) {
                 if (A.advance) {
                     if (A.st.seq_len[slot] < A.max_seq - 1) A.st.seq_len[slot] += 1;
+                    else *A.err = 950;           // KV cache full: GVC_ERR_STATE on the host's next call
                     if (A.st.mel_pos[slot] < A.max_mel_pos - 1) A.st.mel_pos[slot] += 1;
+                    else *A.err = 951;
                 }
                 if (A.step_ctr) *A.step_ctr += 1;
             }
         }
-    }
 #undef GVC_PHASE_BEGIN
+    }
     // ---- end of step: the last workgroup to arrive opens the next epoch ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();

@@ -111,9 +111,10 @@ class GptEngine:
                                ptr(_i32(finished)), C.byref(params), step, ptr(tok), stream()), "sample")
         return tok
 
-    def generate(self, slots, ids, ids_len, finished, params, i0, n_steps, tokens_out, latents_out):
+    def generate(self, slots, ids, ids_len, finished, params, i0, n_steps, tokens_out, latents_out, max_keys=0):
         """tokens_out [B, >= i0+n_steps] int32 and latents_out [B, >= i0+n_steps, d] may be column slices of larger
-        buffers (row strides are passed on); step i of this call lands in column i0 + i."""
+        buffers (row strides are passed on); step i of this call lands in column i0 + i.  max_keys: cached positions of the
+        longest stream after the call (0: unknown, the width of `ids` is taken)."""
         B = slots.shape[0]
         assert tokens_out.is_cuda and tokens_out.dtype == torch.int32 and tokens_out.stride(1) == 1
         lat_stride = 0
@@ -122,7 +123,7 @@ class GptEngine:
             assert latents_out.stride(1) == self.d and latents_out.stride(0) % self.d == 0
             lat_stride = latents_out.stride(0) // self.d
         check(lib().gvc_gpt_generate(self._h, ptr(_i32(slots)), B, ptr(_i32(ids)), ids.shape[1], ptr(_i32(ids_len)),
-                                     ptr(_i32(finished)), C.byref(params), i0, n_steps, ptr(tokens_out),
+                                     ptr(_i32(finished)), C.byref(params), i0, n_steps, int(max_keys), ptr(tokens_out),
                                      tokens_out.stride(0), ptr(latents_out), lat_stride, stream()), "generate")
 
     def time_kernel(self, which, slots, tok, n_steps):
@@ -285,6 +286,7 @@ class HifiganEngine:
             d.res_kernels[j] = k
             d.res_dilations[j][0], d.res_dilations[j][1] = dl
         d.max_batch, d.max_frames = max_batch, max_frames
+        self.max_frames = max_frames
         self.total_up = 1
         for r in cfg["upsample_rates"]:
             self.total_up *= r

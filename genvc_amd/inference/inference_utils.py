@@ -76,11 +76,35 @@ def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=Fa
         clen = torch.tensor([codes.shape[-1]], device=m.device)
         final_latents.append(m.gpt(codes, clen, gen.unsqueeze(0), out_len, cond_latents=cond_latent, return_latent=True))
         all_codes.append(gen)
+    if not final_latents:                    # every segment ended on its first token: nothing to vocode
+        empty = torch.zeros(0, device=m.device)
+        return dict(latents=None, codes=[], wav=empty) if return_details else empty
     latents = torch.cat(final_latents, dim=1)
     wav = _vocode(m, latents)
     if return_details or wav is None:
         return dict(latents=latents, codes=all_codes, wav=None if wav is None else wav[0].squeeze())
     return wav[0].squeeze()
+
+
+@torch.inference_mode()
+def synthesize_utt_chunked(genVC_mdl, src_wav, tgt_audio, seg_len=6.0):
+    """non-streaming conversion with waveform-level concatenation (reference :92-133): every segment goes through
+    `genVC_mdl.inference` (trainers/hifigan_trainer.py:457-500) and the segment waveforms are joined by `handle_chunks`
+    (1024 samples dropped from each, cross-fade over the previous tail)."""
+    m = genVC_mdl
+    wav_gen_prev, wav_overlap = None, None
+    pred_audios = []
+    min_len = int(0.32 * m.content_sample_rate)
+    src_wav = src_wav.to(m.device)
+    seg = int(seg_len * m.content_sample_rate)
+    cond_latent = m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
+    c = m.config
+    for src_seg in segments(src_wav, seg, min_len):
+        audio_pred = m.inference(src_seg, cond_latent, top_p=c.top_p, top_k=c.top_k, temperature=c.temperature,
+                                 length_penalty=c.length_penalty, repetition_penalty=c.repetition_penalty)
+        wav_chunk, wav_gen_prev, wav_overlap = handle_chunks(audio_pred.squeeze(), wav_gen_prev, wav_overlap, 1024)
+        pred_audios.append(wav_chunk)
+    return torch.cat(pred_audios, dim=-1)
 
 
 @torch.inference_mode()

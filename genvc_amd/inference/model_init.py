@@ -33,14 +33,17 @@ class GenVCModel(nn.Module):
                                         num_tokens=c.num_tokens, codebook_dim=c.codebook_dim, hidden_dim=c.hidden_dim,
                                         num_resnet_blocks=c.num_resnet_blocks, kernel_size=c.kernel_size,
                                         num_layers=c.num_layers, use_transposed_convs=False)
-        self.content_sample_rate = c.get("dvae_sample_rate", 16000)
+        # hifigan_trainer.py:146 reads config.content_dvae_config.audio.dvae_sample_rate
+        self.content_sample_rate = (c.get("audio") or {}).get("dvae_sample_rate", c.get("dvae_sample_rate", 16000))
         # ContentVec = HuBERT-base under fairseq's parameter names (hifigan_trainer.py:85); another extractor with
         # the same interface can be passed in
         self.content_extractor = content_extractor or ContentvecExtractor(config.get("hubert_config"))
         v = config.get("vocoder_config")
         if hifigan is None and v is not None:                             # hifigan_trainer.py:47-55
+            # the reference's config spells the field `upsample_kernal_sizes` (configs/vocoder_configs.py:19, hifigan_trainer.py:53)
+            up_kernels = v.get("upsample_kernal_sizes", v.get("upsample_kernel_sizes"))
             hifigan = HiFiGAN(v.input_feat_dim, v.upsample_initial_channel, v.resblock_kernel_sizes,
-                              v.resblock_dilation_sizes, v.upsample_rates, v.upsample_kernel_sizes,
+                              v.resblock_dilation_sizes, v.upsample_rates, up_kernels,
                               resblock_type=v.get("resblock_type", "2"))
         self.hifigan = hifigan
         self.hifigan_scale_factor = a.gpt_code_stride_len / (v.get("hop_length", 256) if v is not None else 256)  # :56
@@ -72,6 +75,28 @@ class GenVCModel(nn.Module):
             embs.append(self.gpt.get_style_emb(mel, None))
         return torch.stack(embs).mean(dim=0).transpose(1, 2).contiguous()
 
+    @torch.no_grad()
+    def inference(self, src_audio, cond_latent, do_sample=True, top_p=0.85, top_k=15, temperature=0.75, num_beams=1,
+                  length_penalty=1.0, repetition_penalty=10.0, output_attentions=False):
+        """reference trainers/hifigan_trainer.py:457-500: one source segment [1,T] + conditioning latents -> waveform
+        [1,1,1024 n]: ContentVec -> content codes -> generate -> strip stop tokens -> latent re-pass -> x4 linear
+        interpolation -> HiFi-GAN.  (The reference's 0-d collapse at exactly one non-stop token, SURVEY appendix B.9, is
+        guarded: boolean indexing keeps the dimension.)"""
+        feat = self.content_extractor.extract_content_features(src_audio)
+        codes = self.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+        gen = self.gpt.generate(cond_latent, codes, do_sample=do_sample, top_p=top_p, top_k=top_k, temperature=temperature,
+                                num_beams=num_beams, length_penalty=length_penalty, repetition_penalty=repetition_penalty,
+                                output_attentions=output_attentions)[0]
+        gen = gen[gen != self.gpt.stop_audio_token]
+        if gen.numel() == 0:
+            return torch.zeros(1, 1, 0, device=self.device)
+        out_len = torch.tensor([gen.shape[-1] * self.config.model_args.gpt_code_stride_len], device=self.device)
+        clen = torch.tensor([codes.shape[-1]], device=self.device)
+        lat = self.gpt(codes, clen, gen.unsqueeze(0), out_len, cond_latents=cond_latent, return_latent=True)
+        mel_input = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[self.hifigan_scale_factor],
+                                                    mode="linear").squeeze(1)
+        return self.hifigan.forward(mel_input)
+
 
 def build_model(config, device, content_extractor=None, hifigan=None, max_slots=8, weight_dtype="fp32"):
     model = GenVCModel(config, content_extractor, hifigan)
@@ -99,7 +124,7 @@ def model_init(checkpoint_path, device, content_extractor=None, hifigan=None, we
     config = gcfg.default_config()
     _merge(config, ckpt["config"])
     model, finish = build_model(config, device, content_extractor, hifigan, weight_dtype=weight_dtype)
-    model.load_state_dict(ckpt["model"], strict=False)                   # model_init.py:22
+    _load_checked(model, ckpt["model"])                                  # model_init.py:22 (strict=False)
     finish()
     print("Model initialized")
     return model, config
@@ -126,6 +151,28 @@ def model_init_synthetic(config=None, seed=1, device="cuda", max_slots=8, weight
     assert not unexpected, unexpected
     finish()
     return model, config
+
+
+_REQUIRED_PREFIXES = ("gpt.", "content_dvae.", "hifigan.", "content_extractor.model.")
+
+
+def _load_checked(model, state):
+    """load_state_dict(strict=False) as the reference does (model_init.py:22: the checkpoint also holds discriminators, the
+    acoustic DVAE ...), but a checkpoint that LACKS a tensor of the inference path would leave a placeholder (zeros / random)
+    in the engines and produce garbage audio silently: those keys are reported.  Weight-norm tensors saved by newer torch
+    (`parametrizations.weight.original0/1`) are renamed to the `weight_g` / `weight_v` the reference's checkpoints carry."""
+    state = dict(state)
+    for k in list(state):
+        if ".parametrizations.weight.original" in k:
+            new = k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v")
+            state[new] = state.pop(k)
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    lost = [k for k in missing if k.startswith(_REQUIRED_PREFIXES)
+            and not k.endswith((".attn.bias", ".attn.masked_bias"))]
+    if lost:
+        raise RuntimeError(f"checkpoint lacks {len(lost)} tensors of the inference path, e.g. {lost[:6]} "
+                           f"(unexpected keys: {len(unexpected)})")
+    return missing, unexpected
 
 
 def _merge(dst, src):

@@ -160,7 +160,7 @@ class GPT(nn.Module):
                   finished=torch.zeros(B, device=dev, dtype=torch.int32),
                   toks=torch.full((B, max_new), self.stop_audio_token, device=dev, dtype=torch.int32),
                   lats=torch.empty(B, max_new, self.model_dim, device=dev, dtype=torch.float32),
-                  max_new=max_new, done=0)
+                  max_new=max_new, done=0, n0=n0)
         samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
                     top_p=kw.get("top_p", 1.0), top_k=kw.get("top_k", 0) if kw.get("do_sample", True) else 1)
         st["params"] = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
@@ -173,8 +173,10 @@ class GPT(nn.Module):
         """n graph-replayed (sample, decode) steps; returns True when every row has emitted the stop token"""
         n = min(n, st["max_new"] - st["done"])
         if n > 0:
+            # the cache holds n0 positions after the prefill and one more per step: the library picks its decode kernels for the
+            # context length this call reaches (not for the 602-token cap the ids rows are sized for)
             self.engine.generate(st["slots"], st["ids"], st["ids_len"], st["finished"], st["params"], st["done"], n,
-                                 st["toks"], st["lats"])
+                                 st["toks"], st["lats"], max_keys=st["n0"] + st["done"] + n)
             st["done"] += n
         return bool(st["finished"].all().item()) or st["done"] >= st["max_new"]
 

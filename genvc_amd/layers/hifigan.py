@@ -50,15 +50,40 @@ class HiFiGAN(nn.Module):
         self._engine.bind(dict(self.state_dict()))
         return self
 
+    # frames of context kept on each side of a window of a long input: the generator's receptive field is +-13 input frames
+    # (conv_pre 3, the k = 7 / dilation 12 ResBlock of the first upsampling stage 6, the rest < 1 each)
+    WINDOW_OVERLAP = 32
+
     @torch.inference_mode()
     def forward(self, x):
+        """x [B,d,T] -> [B,1,T * prod(upsample_rates)].  The reference has no length limit (non-streaming conversion vocodes the
+        latents of ALL segments in one call, inference_utils.py:79-87): inputs beyond the engine's buffers go through it in
+        overlapping windows whose interiors are stitched (every kept sample sees its full receptive field)."""
         if self._engine is None:
             self.bind()
-        return self._engine.forward(x.to(torch.float32).contiguous())
+        x = x.to(torch.float32)
+        T, cap, ov = x.shape[-1], self._engine.max_frames, self.WINDOW_OVERLAP
+        if T <= cap:
+            return self._engine.forward(x.contiguous())
+        up = 1
+        for r in self.cfg["upsample_rates"]:
+            up *= r
+        core = cap - 2 * ov
+        out = []
+        for s in range(0, T, core):
+            lo, hi = max(0, s - ov), min(T, s + core + ov)
+            y = self._engine.forward(x[:, :, lo:hi].contiguous())
+            n = min(core, T - s)
+            out.append(y[:, :, (s - lo) * up:(s - lo + n) * up].clone())
+        return torch.cat(out, dim=-1)
 
     @torch.inference_mode()
     def forward_latents(self, latents, scale=4):
         """latents [B,n,d] -> wav; fuses the harness's F.interpolate(scale_factor=4, mode='linear')"""
         if self._engine is None:
             self.bind()
-        return self._engine.forward_latents(latents.to(torch.float32).contiguous(), scale)
+        latents = latents.to(torch.float32)
+        if latents.shape[1] * scale > self._engine.max_frames:      # long input: the reference's own interpolation call, then windows
+            mel = torch.nn.functional.interpolate(latents.transpose(1, 2), scale_factor=[float(scale)], mode="linear")
+            return self.forward(mel)
+        return self._engine.forward_latents(latents.contiguous(), scale)

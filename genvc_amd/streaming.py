@@ -125,7 +125,7 @@ class StreamSessions:
         lats = torch.empty(B, n, m.gpt.model_dim, device=dev, dtype=torch.float32)
         self.params.seed = self.calls          # a fresh counter-RNG stream per call (only matters for top_k > 1)
         self.calls += 1
-        eng.generate(slots, ids, ids_len, fin, self.params, 0, n, toks, lats)
+        eng.generate(slots, ids, ids_len, fin, self.params, 0, n, toks, lats, max_keys=W - 8)
         self.ids[idx, :W] = ids
         self.ids_len[idx] = ids_len
         self.finished[idx] = fin

@@ -62,7 +62,9 @@ typedef struct gvc_gpt_dims {
     int32_t max_rows;     /* capacity (rows) of one prefill / latent re-pass call, all slots together */
     int32_t weight_dtype; /* 0: fp32 (reference numerics). 1: the c_attn/c_proj/c_fc/mlp c_proj/mel_head matrices are
                              rounded to bf16 at bind time; the decode step and the skinny MFMA path stream bf16 copies (half the HBM bytes),
-                             every product and accumulation stays fp32; KV cache and activations stay fp32 */
+                             every product and accumulation stays fp32; KV cache and activations stay fp32.
+                             2: as 1, and the KV cache holds bf16 too (k / v rounded to nearest even where they enter the cache,
+                             widened to fp32 where the attention kernels use them; half the cache bytes) */
 } gvc_gpt_dims;
 
 int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out);
@@ -151,12 +153,15 @@ int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride,
  * the current logits, stores it at tokens_out[b*tok_stride + i0 + i] and the latent that predicted
  * it at latents_out[(b*lat_stride + i0 + i)*d], then runs the decode step that consumes it.
  * ids / ids_len / finished as in gvc_sample (the caller initialises them from compute_embeddings).
- * ids_stride must cover the whole run of the stream (prefix + 1 + all steps the caller will request): it is the
- * bound on cached positions from which the library picks the short-context kernel variant.
+ * max_keys = cached positions of the longest of these streams once the call has run (prefix + 1 + steps so far + n_steps);
+ * the library picks the kernel variant for that context length and returns GVC_ERR_STATE when it would overflow the KV
+ * cache (max_seq).  0 = unknown: ids_stride (which must then cover the whole run of the stream) is taken as the bound.
+ * With one fp32 stream on a full MI355X the whole decode step is ONE launch (csrc/persist_kernel.h): a hand-off of that
+ * launch that times out (not all of its 256 workgroups resident) makes the NEXT call return GVC_ERR_STATE.
  * ------------------------------------------------------------------------------------------ */
 int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                      int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
-                     int32_t n_steps, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
+                     int32_t n_steps, int32_t max_keys, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
                      int32_t lat_stride, gvc_stream s);
 
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
@@ -165,7 +170,8 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
  * mean microseconds per launch (same-stream launch boundary included) and the number of launches.
  * which = 6: the whole decode step (sampler excluded); which = 16 + X: the whole step WITHOUT class X, so that
  * (whole - without) / launches_per_step is the IN-SITU cost of class X (behind its real predecessor, as rocprofv3
- * sees it); both return microseconds per step.
+ * sees it); both return microseconds per step.  which = 7: the one-launch decode step (csrc/persist_kernel.h), microseconds per
+ * launch.  0..6 and 16+ always time the launch-per-phase step (the fallback of bf16 / multi-stream / partial-GPU contexts).
  * Synchronises the stream; leaves the slots' caches in an undefined state (reset or prefill afterwards). */
 int gvc_gpt_time_kernel(gvc_gpt* ctx, int32_t which, const int32_t* slots, int32_t B, const int32_t* tok_in,
                         int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream s);

@@ -495,3 +495,84 @@ def handle_chunks(wav_gen, wav_overlap, overlap_len=1024):
         fade_in = chunk[:overlap_len] * torch.linspace(0.0, 1.0, overlap_len)
         chunk[:overlap_len] = wav_overlap * torch.linspace(1.0, 0.0, overlap_len) + fade_in
     return chunk, wav_gen[-overlap_len:]
+
+
+# ---------------------------------------------------------------------------
+# row 13 (callers): the three conversion harnesses of inference/inference_utils.py driven on the oracle's own stages.
+# `W` bundles the state dicts: dict(gpt=..., dvae=..., hubert=..., hubert_cfg=..., hifigan=..., vocoder_cfg=..., mel_norms=...,
+# dims=..., sampling=..., max_new=...).  Not pinned as a whole (the reference harness needs a checkpoint): every stage is
+# pinned on its own and the glue follows the cited lines.
+# ---------------------------------------------------------------------------
+
+def _segments(src_wav, seg_len_s, sr=16000):
+    """inference_utils.py:43-50 (and :109-116, :158-165): segment tensors, the last one zero-padded to >= 0.32 s."""
+    out = []
+    for i, end, padded in segment_source(src_wav.shape[-1], seg_len_s, sr):
+        seg = src_wav[:, i:end]
+        if padded > end - i:
+            seg = F.pad(seg, (0, padded - (end - i)), "constant", 0)
+        out.append(seg)
+    return out
+
+
+def _segment_codes(W, seg):
+    """inference_utils.py:52-53: ContentVec features -> content DVAE codes."""
+    feat = hubert_extract_features(W["hubert"], W["hubert_cfg"], seg)
+    return dvae_get_codebook_indices(W["dvae"], feat.transpose(1, 2))
+
+
+def synthesize_utt(W, src_wav, tgt_audio, seg_len=6.0):
+    """inference_utils.py:23-89: per segment generate -> strip stop tokens (:68) -> latent re-pass (:71-76); latents
+    concatenated (:79) -> x4 interpolation + HiFi-GAN (:81-87).  Returns dict(codes=[...], latents, wav)."""
+    cond = get_gpt_cond_latents(W["gpt"], tgt_audio, W["mel_norms"])
+    dims, stop = W["dims"], W["dims"]["stop_audio_token"]
+    lat_all, codes_all = [], []
+    for seg in _segments(src_wav, seg_len):
+        codes = _segment_codes(W, seg)
+        toks, _, _ = generate(W["gpt"], dims, cond, codes, W["sampling"], max_new=W.get("max_new"))
+        gen = toks[0][toks[0] != stop]
+        if gen.numel() == 0:
+            continue
+        lat_all.append(gpt_latents(W["gpt"], dims, cond, codes, gen.unsqueeze(0)))
+        codes_all.append(gen)
+    latents = torch.cat(lat_all, dim=1)
+    return dict(codes=codes_all, latents=latents, wav=vocode_latents(W["hifigan"], W["vocoder_cfg"], latents)[0].squeeze())
+
+
+def synthesize_utt_streaming(W, src_wav, tgt_audio, seg_len=6.0, stream_chunk_size=8):
+    """inference_utils.py:135-217: per segment the (token, latent) stream is cut into groups of stream_chunk_size (the
+    EOS-step pair included, :189-196); each group -> x4 interpolation + HiFi-GAN (:196-202) -> handle_chunks (:203-205).
+    Returns dict(tokens=[[1,n] per group], latents=[[1,n,d] per group], wav)."""
+    cond = get_gpt_cond_latents(W["gpt"], tgt_audio, W["mel_norms"])
+    overlap = None
+    toks_g, lats_g, pred = [], [], []
+    for seg in _segments(src_wav, seg_len):
+        codes = _segment_codes(W, seg)
+        toks, lats, _ = generate(W["gpt"], W["dims"], cond, codes, W["sampling"], max_new=W.get("max_new"))
+        n = toks.shape[1]
+        for g0 in range(0, n, stream_chunk_size):
+            lat = lats[:, g0:g0 + stream_chunk_size]
+            toks_g.append(toks[:, g0:g0 + stream_chunk_size]); lats_g.append(lat)
+            wav = vocode_latents(W["hifigan"], W["vocoder_cfg"], lat).squeeze()
+            chunk, overlap = handle_chunks(wav, overlap)
+            pred.append(chunk)
+    return dict(tokens=toks_g, latents=lats_g, wav=torch.cat(pred, -1))
+
+
+def inference(W, src_seg, cond):
+    """HiFiGANTrainer.inference, trainers/hifigan_trainer.py:457-500: one segment -> waveform [1,1,T]."""
+    codes = _segment_codes(W, src_seg)
+    toks, _, _ = generate(W["gpt"], W["dims"], cond, codes, W["sampling"], max_new=W.get("max_new"))
+    gen = toks[0][toks[0] != W["dims"]["stop_audio_token"]]
+    lat = gpt_latents(W["gpt"], W["dims"], cond, codes, gen.unsqueeze(0))
+    return vocode_latents(W["hifigan"], W["vocoder_cfg"], lat)
+
+
+def synthesize_utt_chunked(W, src_wav, tgt_audio, seg_len=6.0):
+    """inference_utils.py:92-133: per segment `inference` -> waveform-level concatenation through handle_chunks (:127-129)."""
+    cond = get_gpt_cond_latents(W["gpt"], tgt_audio, W["mel_norms"])
+    overlap, pred = None, []
+    for seg in _segments(src_wav, seg_len):
+        chunk, overlap = handle_chunks(inference(W, seg, cond).squeeze(), overlap)
+        pred.append(chunk)
+    return torch.cat(pred, dim=-1)

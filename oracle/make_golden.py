@@ -352,6 +352,10 @@ def main():
                                 keep_rows=[0, 1, 2, 23])
     if want("full"):
         make_gpt(GPT, "full_6s", gcfg.DEFAULT_MODEL_ARGS, seed=2, B=2, Tc=75, n_steps=32, keep_rows=[0, 1, 16])
+    if want("full141"):
+        # the CLI default (seg_len 6 s: Tc = 75, P = 109, 141 steps at 23.4375 tokens/s): one stream whose context grows from
+        # 110 to 251 cached positions, across the 128-key boundary where the launch-per-phase step changes its attention variant
+        make_gpt(GPT, "full_6s_b1", gcfg.DEFAULT_MODEL_ARGS, seed=2, B=1, Tc=75, n_steps=141, keep_rows=[0, 1, 2, 17, 18, 19, 64, 128, 140])
     if want("perceiver"):
         make_perceiver(g_tiny, g_full)
     if want("dvae"):

@@ -19,16 +19,28 @@ tok = torch.zeros(1, device=dev, dtype=torch.int32); lg = torch.empty(1, 1026, d
 L = _lib.lib(); L.gvc_gpt_debug_stamps.restype = C.c_int; L.gvc_gpt_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
 for _ in range(4): eng.decode_step(slots, tok, lg, lt)
 nl = dims["n_layer"]
-hb = np.zeros(2 * (5 * nl + 8), dtype=np.uint64)
+hb = np.zeros(20 * (nl + 2) + 10 * 256, dtype=np.uint64)
 n = L.gvc_gpt_debug_stamps(eng._h, hb.ctypes.data_as(C.c_void_p), -1)
-t0 = int(hb[2 * (5 * nl + 2)])
+t0 = int(hb[20 * (nl + 1)])
 us = lambda v: (int(v) - t0) / 100.0
 names = ["A qkv", "B attn", "C proj", "D fc", "E mlp"]
+W = lambda l, p, k: us(hb[(l * 5 + p) * 4 + k])
 for l in list(range(3)) + [nl - 1]:
-    print(f"layer {l}: " + "  ".join(f"{names[p]} in {us(hb[(l*5+p)*2]):7.2f} out {us(hb[(l*5+p)*2+1]):7.2f}" for p in range(5)))
-print(f"head in {us(hb[(nl*5)*2]):.2f} out {us(hb[(nl*5)*2+1]):.2f}")
-d = np.array([[us(hb[(l*5+p)*2+k]) for p in range(5) for k in range(2)] for l in range(1, nl)])
-per = np.diff(np.concatenate([d[:-1, -1:], d[1:, :]], axis=1), axis=1).mean(axis=0) if nl > 2 else None
-if per is not None:
-    print("mean us per stage (layers 2..): " + "  ".join(f"{names[i//2]}{' wait' if i%2==0 else ' work'} {per[i]:.2f}" for i in range(10)))
-    print(f"mean per layer {np.diff(d[:, -1]).mean():.2f} us")
+    print(f"layer {l}: " + "  ".join(f"{names[p]} in {W(l,p,0):7.2f} out {W(l,p,1):7.2f}" for p in range(5)))
+print(f"head in {W(nl,0,0):.2f} out {W(nl,0,1):.2f}")
+d = np.array([[W(l, p, k) for p in range(5) for k in range(2)] for l in range(1, nl)])
+per = np.diff(np.concatenate([d[:-1, -1:], d[1:, :]], axis=1), axis=1).mean(axis=0)
+print("workgroup 0, mean us per stage (layers 2..): " + "  ".join(f"{names[i//2]}{' wait' if i%2==0 else ' work'} {per[i]:.2f}" for i in range(10)))
+print(f"mean per layer {np.diff(d[:, -1]).mean():.2f} us")
+ex = np.array([[W(l, 0, 2) - W(l, 0, 0), W(l, 0, 3) - W(l, 0, 2), W(l, 0, 1) - W(l, 0, 3),
+                W(l, 1, 2) - W(l, 1, 0), W(l, 1, 3) - W(l, 1, 2), W(l, 1, 1) - W(l, 1, 3)] for l in range(2, nl)]).mean(axis=0)
+print("A: LN %.2f rows %.2f publish %.2f | B: scores+fold %.2f combine barrier %.2f merge+publish %.2f" % tuple(ex))
+# every workgroup at layer 2
+b2 = 20 * (nl + 2)
+a2 = np.array([[us(hb[b2 + (w * 5 + p) * 2 + k]) for p in range(5) for k in range(2)] for w in range(256)])
+ref = a2[:, 0].min()
+lab = [f"{names[p]} {'in' if k == 0 else 'out'}" for p in range(5) for k in range(2)]
+for j in range(10):
+    col = a2[:, j]
+    col = col[col > 0] if j in (2, 3) else col
+    print(f"layer 2 {lab[j]:11s}: min {col.min()-ref:6.2f} median {np.median(col)-ref:6.2f} max {col.max()-ref:6.2f}  (n={len(col)})")
