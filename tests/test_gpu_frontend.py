@@ -48,7 +48,7 @@ def test_dvae_codes_match_reference(gold):
     from genvc_amd.engine import DvaeEngine, vq_argmin
     g = gold("dvae")
     seed = int(g["seed"])
-    n_safe = n_all = 0
+    n_safe = n_all = n_exempt_diff = 0
     for tag, c in (("tiny", gcfg.TINY_CONTENT_DVAE), ("full", gcfg.DEFAULT_CONTENT_DVAE)):
         w = synth.make_weights(seed, synth.dvae_weight_spec(c), device=DEV)
         eng = DvaeEngine(c, max_batch=2, max_frames=304)
@@ -63,11 +63,15 @@ def test_dvae_codes_match_reference(gold):
             safe = g[f"{tag}_margin_{B}_{T}"] > 1e-4
             n_safe += int(safe.sum()); n_all += safe.size
             assert np.array_equal(codes.cpu().numpy()[safe], ref[safe])
+            n_exempt_diff += int((codes.cpu().numpy()[~safe] != ref[~safe]).sum())
             # standalone VQ entry point on the same encoder output
             idx = vq_argmin(enc.reshape(-1, enc.shape[-1]).contiguous(), w["codebook.embed"])
             assert torch.equal(idx.view_as(codes), codes)
         eng.close()
     assert n_safe > 0.97 * n_all          # the margin screen excludes only a handful of frames
+    # ... and how many of the exempt (near-tie) frames actually differ: the count is printed with `pytest -s` and bounded
+    print(f"DVAE codes: {n_all} frames, {n_all - n_safe} with a reference margin <= 1e-4, {n_exempt_diff} of those differ")
+    assert n_exempt_diff <= max(2, (n_all - n_safe) // 4)
 
 
 def test_vq_first_index_wins_ties():

@@ -13,8 +13,10 @@ _cache = {}
 
 
 def setup(model_args, seed, max_slots=8, head_bias=None):
+    import os
     from genvc_amd.engine import GptEngine
-    key = (model_args["gpt_layers"], model_args["gpt_n_model_channels"], seed, max_slots, head_bias)
+    # (the context reads GVC_PERSIST when it is created: a test that switches the decode path gets its own context)
+    key = (model_args["gpt_layers"], model_args["gpt_n_model_channels"], seed, max_slots, head_bias, os.environ.get("GVC_PERSIST"))
     if key not in _cache:
         _cache.clear()
         torch.cuda.empty_cache()
@@ -119,6 +121,67 @@ def test_full_tokens_and_logits_match_reference(gold):
 
 def test_full_6s_batch2_matches_reference(gold):
     check_golden(gold("gpt_full_6s"), gcfg.DEFAULT_MODEL_ARGS)
+
+
+@pytest.mark.parametrize("persist", ["1", "0"], ids=["one_launch_step", "launch_per_phase"])
+def test_full_6s_one_stream_141_steps_match_reference(gold, persist, monkeypatch):
+    """the CLI default segment (seg_len 6 s: Tc 75, 141 tokens) at full size, one stream: the context grows from 110 to 251
+    cached positions -- 4 to 8 key chunks in the one-launch step; across the 128-key switch from the fused short-context
+    attention to split-key attention + merge GEMV on the launch-per-phase path.  Tokens bit-exact, logits <= 1e-4."""
+    monkeypatch.setenv("GVC_PERSIST", persist)
+    g = gold("gpt_full_6s_b1")
+    dims, w, eng, cond, codes, toks, lats = check_golden(g, gcfg.DEFAULT_MODEL_ARGS)
+    dev = "cuda"
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    slots = torch.arange(1, device=dev, dtype=torch.int32)
+    logits, latent = eng.prefill(slots, prefix)
+    rows = [int(r) for r in g["logit_rows"]]
+    got = {0: logits.cpu().numpy()}
+    for i in range(1, max(rows) + 1):
+        logits, latent = eng.decode_step(slots, toks[:, i - 1].to(dev).int().contiguous())
+        if i in rows:
+            got[i] = logits.cpu().numpy()
+    for j, r in enumerate(rows):
+        np.testing.assert_allclose(got[r], g["logits"][j], atol=1e-4)
+    _cache.clear()
+
+
+@pytest.mark.parametrize("persist", ["1", "0"], ids=["one_launch_step", "launch_per_phase"])
+def test_kv_cache_overflow_is_reported(persist, monkeypatch):
+    """a generate call whose key bound exceeds max_seq is refused with GVC_ERR_STATE; eager decode steps that fill the cache
+    stop advancing the slot and the NEXT call reports it (no silent clamp)."""
+    from genvc_amd._lib import GenvcHipError
+    from genvc_amd.engine import GptEngine, sample_params
+    monkeypatch.setenv("GVC_PERSIST", persist)
+    dims = dict(gcfg.gpt_dims(gcfg.TINY_MODEL_ARGS), max_seq=64)
+    w = synth.make_weights(3, synth.gpt_weight_spec(dims), device="cuda")
+    eng = GptEngine(dims, max_slots=2, max_rows=256)
+    eng.bind(w)
+    dev = "cuda"
+    cond = synth.uniform(1, "c", (1, 32, dims["d_model"]), 1.0).to(dev)
+    codes = synth.integers(1, "k", (1, 9), 256).to(dev).int()
+    prefix = eng.prefix_embeddings(cond, codes)                       # P = 43 -> 44 cached positions after the prefill
+    slots = torch.zeros(1, device=dev, dtype=torch.int32)
+    eng.prefill(slots, prefix, want_outputs=False)
+    P = prefix.shape[1]
+    ids = torch.ones(1, 128, device=dev, dtype=torch.int32); ids[:, P] = dims["start_audio_token"]
+    ids_len = torch.full((1,), P + 1, device=dev, dtype=torch.int32)
+    fin = torch.zeros(1, device=dev, dtype=torch.int32)
+    toks = torch.zeros(1, 40, device=dev, dtype=torch.int32)
+    sp = sample_params(GREEDY, dims["num_audio_tokens"], -1, 0)
+    with pytest.raises(GenvcHipError, match="overflow"):
+        eng.generate(slots, ids, ids_len, fin, sp, 0, 24, toks, None, max_keys=P + 1 + 24)      # 68 > 63
+    eng.generate(slots, ids, ids_len, fin, sp, 0, 8, toks, None, max_keys=P + 1 + 8)            # fits
+    tok = torch.zeros(1, device=dev, dtype=torch.int32)
+    with pytest.raises(GenvcHipError, match="full"):
+        for _ in range(16):                                                                      # 52 + 16 > 63
+            eng.decode_step(slots, tok)
+            torch.cuda.synchronize()
+    eng.reset(slots)                                                                             # acknowledged: usable again
+    eng.prefill(slots, prefix, want_outputs=False)
+    eng.decode_step(slots, tok)
+    torch.cuda.synchronize()
+    eng.close()
 
 
 def test_decode_from_empty_cache_vs_oracle():

@@ -69,6 +69,100 @@ def test_generate_stops_like_the_reference_on_eos(gold):
     _m.clear()
 
 
+def oracle_bundle(m, max_new):
+    """the model's own (synthetic) weights as the oracle's state dicts"""
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    return dict(gpt=sub("gpt."), dvae=sub("content_dvae."), hubert=sub("content_extractor.model."),
+                hubert_cfg=m.content_extractor.cfg, hifigan=sub("hifigan."), vocoder_cfg=m.hifigan.cfg,
+                mel_norms=m.torch_mel_spectrogram_style_encoder.mel_norms, dims=m.gpt.dims(),
+                sampling=dict(gcfg.DEFAULT_SAMPLING, top_k=1), max_new=max_new)
+
+
+@pytest.mark.parametrize("n_samples,n_chunks", [(72000, 1), (240000, 2), (744000, 5), (148800, 1), (7000, None)],
+                         ids=["3s", "10s=6+4", "31s->30s cap", "6.2s: 0.2s tail skipped", "0.29s: nothing left"])
+def test_cond_latents_chunking_matches_oracle(n_samples, n_chunks):
+    """SURVEY row a2 (trainers/hifigan_trainer.py:438-455): truncate to 30 s, 6 s chunks, chunks under 0.33 s skipped, mean of
+    the Perceiver outputs -- GenVCModel.get_gpt_cond_latents (mel + Perceiver on the HIP path) against the oracle"""
+    from oracle import genvc_oracle as O
+    m = tiny_model(3)
+    W = oracle_bundle(m, 8)
+    ref = synth.synth_audio(21, "ref", n_samples)
+    if n_chunks is None:                     # the reference fails on torch.stack([]) when every chunk is skipped: so do both
+        with pytest.raises(RuntimeError):
+            m.get_gpt_cond_latents(ref.to(DEV), 24000)
+        with pytest.raises(RuntimeError):
+            O.get_gpt_cond_latents(W["gpt"], ref, W["mel_norms"])
+        return
+    got = m.get_gpt_cond_latents(ref.to(DEV), 24000)
+    exp = O.get_gpt_cond_latents(W["gpt"], ref, W["mel_norms"])
+    assert got.shape == exp.shape == (1, 32, 256)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), atol=2e-4)
+    # the chunk count the mean was taken over: a single-chunk reference equals its own style embedding
+    if n_chunks == 1:
+        first = O.get_gpt_cond_latents(W["gpt"], ref[:, :144000], W["mel_norms"])
+        np.testing.assert_allclose(exp.numpy(), first.numpy(), atol=1e-6)
+
+
+def test_harnesses_match_the_oracle_driven_through_the_same_segmentation():
+    """streamed tokens / latents / waveform of a whole utterance (3 segments, the last one zero-padded; groups
+    of 8 with the EOS-step latent; cross-faded vocoder chunks) and the non-streaming and chunked conversions, each against
+    the ORACLE's restatement of the same harness run on the same weights (not streaming-vs-non-streaming)."""
+    from genvc_amd.inference.inference_utils import synthesize_utt, synthesize_utt_chunked, synthesize_utt_streaming
+    from oracle import genvc_oracle as O
+    m = tiny_model(3)
+    m.gpt.max_gen_mel_tokens = 20
+    W = oracle_bundle(m, 20)
+    src = synth.synth_audio(5, "src", 36000)                       # 1 s + 1 s + 0.25 s (padded to 0.32 s)
+    ref = synth.synth_audio(6, "ref", 72000)
+    # streaming
+    st = synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+    ex = O.synthesize_utt_streaming(W, src, ref, seg_len=1.0, stream_chunk_size=8)
+    assert [t.shape[1] for t in st["tokens"]] == [t.shape[1] for t in ex["tokens"]]          # same group boundaries
+    assert torch.equal(torch.cat(st["tokens"], 1).cpu(), torch.cat(ex["tokens"], 1))          # same tokens, EOS steps included
+    np.testing.assert_allclose(torch.cat(st["latents"], 1).cpu().numpy(), torch.cat(ex["latents"], 1).numpy(), atol=2e-4)
+    assert st["wav"].shape == ex["wav"].shape
+    np.testing.assert_allclose(st["wav"].cpu().numpy(), ex["wav"].numpy(), atol=1e-3)
+    # non-streaming, latent-level concatenation
+    ns = synthesize_utt(m, src, ref, seg_len=1.0, return_details=True)
+    en = O.synthesize_utt(W, src, ref, seg_len=1.0)
+    assert torch.equal(torch.cat(ns["codes"]).cpu(), torch.cat(en["codes"]))
+    np.testing.assert_allclose(ns["latents"].cpu().numpy(), en["latents"].numpy(), atol=2e-4)
+    np.testing.assert_allclose(ns["wav"].cpu().numpy(), en["wav"].numpy(), atol=1e-3)
+    # chunked: model.inference per segment + waveform-level concatenation (inference_utils.py:92-133)
+    ch = synthesize_utt_chunked(m, src, ref, seg_len=1.0)
+    ec = O.synthesize_utt_chunked(W, src, ref, seg_len=1.0)
+    assert ch.shape == ec.shape
+    np.testing.assert_allclose(ch.cpu().numpy(), ec.numpy(), atol=1e-3)
+    # model.inference with the reference's argument list on one segment
+    cond = m.get_gpt_cond_latents(ref.to(DEV), 24000)
+    one = m.inference(src[:, :16000].to(DEV), cond, top_k=1, top_p=0.85, temperature=0.85, repetition_penalty=2.0)
+    eo = O.inference(W, src[:, :16000], O.get_gpt_cond_latents(W["gpt"], ref, W["mel_norms"]))
+    assert one.shape == eo.shape and one.dim() == 3
+    np.testing.assert_allclose(one.cpu().numpy(), eo.numpy(), atol=1e-3)
+    _m.clear()
+
+
+def test_long_latent_sequences_are_vocoded_in_windows():
+    """the reference's non-streaming path vocodes the latents of ALL segments in one call (inference_utils.py:79-87): inputs
+    beyond the engine's buffers run through overlapping windows and equal the one-shot oracle"""
+    from genvc_amd.layers.hifigan import HiFiGAN
+    from oracle import genvc_oracle as O
+    c = gcfg.TINY_VOCODER
+    v = HiFiGAN(c["input_feat_dim"], c["upsample_initial_channel"], c["resblock_kernel_sizes"], c["resblock_dilation_sizes"],
+                c["upsample_rates"], c["upsample_kernel_sizes"], resblock_type="2")
+    w = synth.make_weights(13, synth.hifigan_weight_spec(c))
+    v.load_state_dict(w)
+    v.to(DEV).bind(max_batch=1, max_frames=256)
+    lat = synth.uniform(13, "long", (1, 170, c["input_feat_dim"]), 1.0)           # 680 frames = 3.5 windows of 192 + overlap
+    got = v.forward_latents(lat.to(DEV), 4)
+    exp = O.vocode_latents(w, c, lat)
+    assert got.shape == exp.shape == (1, 1, 170 * 1024)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), atol=1e-4)
+    mel = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[4.0], mode="linear")
+    np.testing.assert_allclose(v(mel.to(DEV)).cpu().numpy(), exp.numpy(), atol=1e-4)
+
+
 def test_harness_streaming_and_offline_agree():
     from genvc_amd.inference.inference_utils import synthesize_utt, synthesize_utt_streaming
     from genvc_amd.parallel_offline import convert_offline

@@ -121,6 +121,30 @@ def test_handle_chunks_matches_reference_fixture(gold):
             np.testing.assert_array_equal(ov.numpy(), g[f"overlap{i}"])
 
 
+def test_model_init_reads_the_reference_config_shape_and_reports_lost_tensors():
+    """a config dict shaped like the reference's Coqpit dump (configs/vocoder_configs.py:19 `upsample_kernal_sizes`,
+    hifigan_trainer.py:146 `content_dvae_config.audio.dvae_sample_rate`) and a checkpoint without a tensor of the path"""
+    from genvc_amd.inference.model_init import GenVCModel, _load_checked, _merge
+    cfg = gcfg.default_config(tiny=True)
+    ck = {"vocoder_config": {"upsample_kernal_sizes": [4, 4, 8]},
+          "content_dvae_config": {"audio": {"dvae_sample_rate": 22050}}}
+    _merge(cfg, ck)
+    cfg.vocoder_config.upsample_rates = [2, 2, 4]
+    del cfg.vocoder_config["upsample_kernel_sizes"]
+    m = GenVCModel(cfg)
+    assert m.hifigan.cfg["upsample_kernel_sizes"] == [4, 4, 8] and m.content_sample_rate == 22050
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # newer-torch weight-norm names are accepted
+    g = sd.pop("hifigan.conv_pre.weight_g"); v = sd.pop("hifigan.conv_pre.weight_v")
+    sd["hifigan.conv_pre.parametrizations.weight.original0"], sd["hifigan.conv_pre.parametrizations.weight.original1"] = g, v
+    sd["discriminator.something"] = torch.zeros(3)                      # training-only tensors are ignored (strict=False)
+    missing, unexpected = _load_checked(m, sd)
+    assert not [k for k in missing if k.startswith("hifigan.")] and unexpected == ["discriminator.something"]
+    del sd["gpt.gpt.h.1.mlp.c_fc.weight"]
+    with pytest.raises(RuntimeError, match="c_fc"):
+        _load_checked(m, sd)
+
+
 def test_stop_len_rule():
     from genvc_amd.layers.gpt import GPT
     g = GPT(layers=1, model_dim=256, heads=4)
