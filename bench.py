@@ -16,6 +16,15 @@ fixed: round(1 s * 23.4375) = 23 tokens + the EOS step = 24 decode steps per chu
 N > 1: one process per GPU, utterances sharded by rank, no collective on the data path; the generated
 token ids are all-gathered (RCCL) inside the timed region.  value = utterances/s of the whole job.
 
+Extra legs, outside the K timed steps (their numbers are extra keys of the same JSON line):
+  * `offline` (every rank): BASELINE configs[2] -- 64 synthetic 10 s utterances (segments 6 s + 4 s, 141 + 94 tokens, top_k=1)
+    through parallel_offline.convert_offline: utterances sharded over the ranks, a FIXED micro-batch of 8 utterances per
+    GPU, no collective while converting, ONE all_gather of the token ids at the end.  N = 1 also reports the fully batched
+    figure (a decode step streams the weights once whatever the batch, so only the fixed-micro-batch number
+    scales with GPUs).  `--no-offline` skips it.
+  * `harness` (rank 0): the same utterance through inference_utils.synthesize_utt_streaming with the inputs in HOST memory --
+    the reference's latency window (clock before the host->device copy, inference_utils.py:148) next to the device-only one.
+
 `--streams B` (default 1 = the headline configuration) steps B concurrent streams per GPU together (BASELINE
 configs[3] shape: shared launches, one decode step for all streams; the MFMA rows path from 5 streams up); a step is
 then B utterances and the JSON line says so in `config.workload`.
@@ -41,6 +50,7 @@ GROUP = 8                                     # stream_chunk_size of the referen
 KERNEL_NAMES = ["c_attn_gemv(ln1+qkv)", "attention+attn_c_proj(fused,head-split)", "attn_c_proj_gemv(unfused path only)",
                 "mlp_c_fc_gemv(resid-sum+ln2+gelu)", "mlp_c_proj_gemv(resid)", "head_gemv(2xln+mel_head)"]
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+OFFLINE_UTTS, OFFLINE_MICRO_BATCH = 64, 8     # BASELINE configs[2]; fixed per-GPU micro-batch
 
 
 def kernel_bytes(dims, which, S, wb=4, kvb=4):
@@ -61,12 +71,20 @@ def kernel_bytes(dims, which, S, wb=4, kvb=4):
     return V * d * wb + (V + 4 * d + d + V + d) * f
 
 
+def step_bytes(dims, S, wb=4, kvb=4):
+    """algorithmic bytes of one whole decode step of one stream with S cached positions: every weight once,
+    the K/V rows of S positions read, one position written"""
+    d, V, L = dims["d_model"], dims["num_audio_tokens"], dims["n_layer"]
+    w_dec = L * (12 * d * d + 13 * d) + 4 * d + (d * V + V) + 2 * d
+    return w_dec * wb + (2 * L * S * d + 2 * L * d) * kvb
+
+
 class Workload:
-    def __init__(self, device, rank, streams=1, weight_dtype="fp32"):
+    def __init__(self, device, rank, streams=1, weight_dtype="fp32", max_slots=8):
         from genvc_amd.inference.model_init import model_init_synthetic
         self.dev = device
         self.S = S = streams
-        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=max(8, S),
+        self.model, self.config = model_init_synthetic(gcfg.default_config(), seed=1, device=device, max_slots=max(max_slots, S),
                                                        weight_dtype=weight_dtype)
         m = self.model
         self.dims = m.gpt.dims()
@@ -114,7 +132,8 @@ class Workload:
             tok_view = self.toks[:, base:base + STEPS_PER_CHUNK]
             lat_view = self.lats[:, base:base + STEPS_PER_CHUNK]
             for g in range(0, STEPS_PER_CHUNK, GROUP):
-                eng.generate(self.slots, self.ids, self.ids_len, self.fin, self.sp, g, GROUP, tok_view, lat_view)
+                eng.generate(self.slots, self.ids, self.ids_len, self.fin, self.sp, g, GROUP, tok_view, lat_view,
+                             max_keys=self.P + 1 + g + GROUP)
                 # vocoder every 8 tokens (x4 interpolation + HiFi-GAN -> 8192 samples), inference_utils.py:195-205
                 self.wav = m.hifigan.forward_latents(lat_view[:, g:g + GROUP], 4)
                 if record and c == 0 and g == 0:
@@ -175,8 +194,72 @@ def cpu_baseline(wl, budget_s=10.0):
     return {"value": 1.0 / utt_s, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} of {wl.n_chunks} one-second chunks of one utterance (ContentVec, DVAE+VQ, prefill 48 rows, "
                       f"{STEPS_PER_CHUNK} decode steps each) + mel/Perceiver once; extrapolated to the full utterance",
-            "ms_per_chunk": t_chunk * 1e3, "ms_per_decode_token_est": t_chunk * 1e3 / (STEPS_PER_CHUNK + 2),
+            "ms_per_chunk": t_chunk * 1e3, "ms_per_chunk_min_max": [min(times) * 1e3, max(times) * 1e3],
+            "note": "host load moves this figure by +-20 % from run to run (0.05-0.07 utterances/s observed); context, not a target",
+            "ms_per_decode_token_est": t_chunk * 1e3 / (STEPS_PER_CHUNK + 2),
             "rtf": utt_s / SRC_SECONDS, "host_cpus": os.cpu_count(), "cpu": platform.processor() or platform.machine()}
+
+
+def offline_leg(wl, rank, world, dist, device):
+    """BASELINE configs[2] through parallel_offline.convert_offline (see the module docstring).  Every rank runs it."""
+    from genvc_amd.parallel_offline import convert_offline
+    m = wl.model
+    top_k = m.config.top_k
+    m.config.top_k = 1
+    srcs = [synth.synth_audio(500 + i, "src", int(SRC_SECONDS * 16000)) for i in range(OFFLINE_UTTS)]
+    ref = synth.synth_audio(7, "ref", int(REF_SECONDS * 24000))
+    kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141)
+
+    def run(mb, r, w):
+        convert_offline(m, srcs[:mb * w], ref, micro_batch=mb, rank=r, world=w, **kw)        # graph capture / warm-up, one wave
+        torch.cuda.synchronize()
+        if dist is not None and w > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        toks = convert_offline(m, srcs, ref, micro_batch=mb, rank=r, world=w, **kw)          # ONE all_gather at its end
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None and w > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert toks.shape[0] == OFFLINE_UTTS
+        return OFFLINE_UTTS / dt
+
+    out = {"workload": f"{OFFLINE_UTTS} synthetic 10 s utterances (segments 6 s + 4 s: 141 + 94 tokens, fixed budget), top_k=1, tokens "
+                       "only (BASELINE configs[2]); utterances sharded over the ranks, one all_gather of the token ids at the end",
+           "micro_batch_utterances_per_gpu": OFFLINE_MICRO_BATCH, "n_gpus": world,
+           "offline_utts_per_s": run(OFFLINE_MICRO_BATCH, rank, world)}
+    if world == 1:
+        out["offline_utts_per_s_fully_batched_1gpu"] = run(OFFLINE_UTTS, 0, 1)
+        out["note"] = ("a decode step streams the weights once whatever the batch: the fully batched figure is what one GPU can do, the "
+                       "fixed-micro-batch figure is the one that scales with the GPU count (SURVEY.md 8e)")
+    m.config.top_k = top_k
+    return out
+
+
+def harness_leg(wl, reps=3):
+    """the headline utterance through the reference-shaped harness, inputs in host memory (reference latency window)"""
+    from genvc_amd.inference.inference_utils import synthesize_utt_streaming
+    m = wl.model
+    top_k = m.config.top_k
+    m.config.top_k = 1
+    cap = m.gpt.max_gen_mel_tokens
+    m.gpt.max_gen_mel_tokens = STEPS_PER_CHUNK          # fixed token budget per 1 s chunk, as in the timed workload
+    src = synth.synth_audio(200, "src", int(SRC_SECONDS * 16000))
+    ref = synth.synth_audio(100, "ref", int(REF_SECONDS * 24000))
+    synthesize_utt_streaming(m, src, ref, seg_len=CHUNK_SECONDS, stream_chunk_size=GROUP, verbose=False, return_details=True)
+    lat, rtf = [], []
+    for _ in range(reps):
+        r = synthesize_utt_streaming(m, src, ref, seg_len=CHUNK_SECONDS, stream_chunk_size=GROUP, verbose=False, return_details=True)
+        lat.append(r["latency"] * 1e3)
+        rtf.append(r["rtf"])
+    m.gpt.max_gen_mel_tokens = cap
+    m.config.top_k = top_k
+    return {"path": "inference_utils.synthesize_utt_streaming(model, src_wav[host], ref[host], seg_len=1.0, stream_chunk_size=8)",
+            "rtf": sum(rtf) / len(rtf), "first_chunk_latency_ms": sum(lat) / len(lat), "first_chunk_latency_ms_min_max": [min(lat), max(lat)],
+            "window": "host clock from before the host->device copies to the first vocoder chunk, device synchronised "
+                      "(the reference reads its clock without a sync, inference_utils.py:148,208-211)", "runs": reps}
 
 
 def main():
@@ -185,6 +268,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-offline", action="store_true", help="skip the batched-offline leg (BASELINE configs[2])")
+    ap.add_argument("--no-harness", action="store_true", help="skip the harness-level leg")
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
     ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv"],
                     help="GPT weight / KV-cache storage (fp32 = headline configuration; bf16_kv with --streams 8 = BASELINE configs[3])")
@@ -217,7 +302,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    wl = Workload(device, rank, args.streams, args.weights)
+    headline = args.streams == 1
+    do_offline = headline and not args.no_offline and args.weights == "fp32"
+    slots_needed = max(8, OFFLINE_UTTS if (do_offline and world == 1) else OFFLINE_MICRO_BATCH)
+    wl = Workload(device, rank, args.streams, args.weights, max_slots=slots_needed)
     for u in range(args.warmup):
         wl.utterance(u)
 
@@ -242,20 +330,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    offline = offline_leg(wl, rank, world, dist, device) if do_offline else None
+
     if rank == 0:
         # latency / per-stage numbers from one recorded utterance (device events on the launch stream)
         wl.utterance(0, record=True)
         torch.cuda.synchronize()
         first_ms = wl.ev[0].elapsed_time(wl.ev[1])
         utt_ms = wl.ev[0].elapsed_time(wl.ev[2])
-        # per-kernel timing of the decode step: each class launched back to back across the layers between two
-        # HIP events on the launch stream (gvc_gpt_time_kernel); mean per launch, launch boundary included
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (gvc_gpt_time_kernel) ----
         S = wl.P + 1 + STEPS_PER_CHUNK // 2
         tok = torch.zeros(1, device=device, dtype=torch.int32)
         s1 = wl.slots[:1].contiguous()
-        # whole step and the step without each class, replayed back to back between two HIP events on the launch stream:
-        # in-situ cost of a class = (whole - without) / launches.  (Single-kernel event pairs are useless at 5 us; a class
-        # launched alone re-reads its own stale inputs from L2 and looks 5-12 % faster than rocprofv3 sees it in the step.)
+
         def fresh():
             wl.eng.prefill(s1, wl.eng.prefix_embeddings(wl.model.get_gpt_cond_latents(wl.ref[0], 24000),
                                                         torch.zeros(1, wl.Tc, device=device, dtype=torch.int32)), want_outputs=False)
@@ -263,27 +350,40 @@ def main():
         wb = 4 if args.weights == "fp32" else 2
         kvb = 2 if args.weights == "bf16_kv" else 4
         fresh()
-        whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)
+        whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)          # launch-per-phase step (the fallback path; the bf16 contexts' path)
+        one_launch = args.weights == "fp32" and os.environ.get("GVC_PERSIST", "1") != "0"
         kern = []
-        for which in range(6):
-            per_step = 1 if which == 5 else wl.dims["n_layer"]
+        if one_launch:
+            # the one-stream decode step is ONE launch (csrc/persist_kernel.h) = 80 % of the utterance: it IS the dominant kernel.
+            # `reps` launches replayed from a graph between two events; the context grows from wl.P + 1 by one position per launch
             fresh()
-            iso, n = wl.eng.time_kernel(which, s1, tok, 128 if which == 5 else 32)
-            if n == 0:
-                continue
-            fresh()
-            without_us, _ = wl.eng.time_kernel(16 + which, s1, tok, reps)
-            kern.append({"kernel": KERNEL_NAMES[which], "avg_us": (whole_us - without_us) / per_step, "avg_us_launched_alone": iso,
-                         "launches_per_step": per_step, "bytes": kernel_bytes(wl.dims, which, S, wb, kvb)})
-        # dominant = the weight-streaming GEMV with the largest share of the step (the fused attention launch is
-        # L2/latency-bound, not an HBM stream, so it is listed but not used as the roofline kernel)
-        cand = [i for i, k in enumerate(kern) if "gemv" in k["kernel"] and "head" not in k["kernel"]]
-        dom = max(cand, key=lambda i: kern[i]["avg_us"] * kern[i]["launches_per_step"])
+            step_us, n = wl.eng.time_kernel(7, s1, tok, 24)
+            s_mid = wl.P + 1 + 12
+            kern.append({"kernel": "k_decode_persist<4> (whole decode step of one stream, one launch)", "avg_us": step_us,
+                         "launches_per_step": 1, "bytes": step_bytes(wl.dims, s_mid, wb, kvb)})
+            dom = 0
+        else:
+            # whole step and the step without each class, replayed back to back: in-situ cost of a class = (whole - without) /
+            # launches.  (Single-kernel event pairs are useless at 5 us; a class launched alone re-reads its own stale inputs
+            # from L2 and looks 5-12 % faster than rocprofv3 sees it in the step.)
+            for which in range(6):
+                per_step = 1 if which == 5 else wl.dims["n_layer"]
+                fresh()
+                iso, n = wl.eng.time_kernel(which, s1, tok, 128 if which == 5 else 32)
+                if n == 0:
+                    continue
+                fresh()
+                without_us, _ = wl.eng.time_kernel(16 + which, s1, tok, reps)
+                kern.append({"kernel": KERNEL_NAMES[which], "avg_us": (whole_us - without_us) / per_step, "avg_us_launched_alone": iso,
+                             "launches_per_step": per_step, "bytes": kernel_bytes(wl.dims, which, S, wb, kvb)})
+            # dominant = the weight-streaming GEMV with the largest share of the step
+            cand = [i for i, k in enumerate(kern) if "gemv" in k["kernel"] and "head" not in k["kernel"]]
+            dom = max(cand, key=lambda i: kern[i]["avg_us"] * kern[i]["launches_per_step"])
         achieved = kern[dom]["bytes"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and args.weights == "fp32":      # the PMC passes were taken on the fp32 build
-            traffic = json.load(open(pmc)).get(kern[dom]["kernel"])
+            traffic = json.load(open(pmc)).get(kern[dom]["kernel"].split(" ")[0])
         n_utts = args.steps * world * args.streams
         ms_step = dt / args.steps * 1e3
         out = {
@@ -292,6 +392,8 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.weights == "fp32" else "bf16 storage, f32 arithmetic", "data": "synthetic", "weights": args.weights,
             "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms, "streams_per_gpu": args.streams,
+            "first_chunk_latency_window": "device events, inputs resident in HBM (the harness-level window with the host->device "
+                                          "copies inside is `harness.first_chunk_latency_ms`)",
             "ms_per_utterance_device": utt_ms,
             "config": {"workload": ("GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU (BASELINE configs[1])" if args.streams == 1
                                     else f"GenVC_small streaming, 1 s chunks, top_k=1, {args.streams} concurrent streams per GPU stepped together "
@@ -304,9 +406,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": kern[dom]["bytes"], "avg_us": kern[dom]["avg_us"],
-                         "decode_step_us": whole_us},
+                         "decode_step_us": kern[dom]["avg_us"] if one_launch else whole_us,
+                         "decode_step_us_launch_per_phase": whole_us},
             "kernels": kern,
         }
+        if offline is not None:
+            out["offline"] = offline
+            out["offline_utts_per_s"] = offline["offline_utts_per_s"]
+        if headline and not args.no_harness:
+            out["harness"] = harness_leg(wl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))

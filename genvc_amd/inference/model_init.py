@@ -106,7 +106,8 @@ def build_model(config, device, content_extractor=None, hifigan=None, max_slots=
 def _finish(model, device, max_slots, weight_dtype="fp32"):
     model.eval()
     model.to(device)
-    model.gpt.init_gpt_for_inference(max_slots=max_slots, weight_dtype=weight_dtype)
+    # prefill capacity: every slot may bring a 6 s segment (110 rows) into one batched call
+    model.gpt.init_gpt_for_inference(max_slots=max_slots, max_rows=max(4096, 128 * max_slots), weight_dtype=weight_dtype)
     mb = max(2, max_slots)
     model.content_dvae.bind(max_batch=max(8, max_slots))
     if hasattr(model.content_extractor, "bind"):

@@ -195,3 +195,96 @@ def test_data_parallel_gather_world2(n_total):
     exp = np.stack([np.full((2, 6), 100 * j, np.int32) + np.arange(6, dtype=np.int32) for j in range(n_total)])
     for r in range(2):
         assert np.array_equal(res[r], exp)            # every rank holds all utterances in order
+
+
+class _StubModel:
+    """duck-typed GenVCModel for the CPU test of the offline driver: every stage is a cheap deterministic function of its input
+    (so any mix-up of utterances, segments or ranks changes the token ids), with the shapes of the real stages"""
+    device = torch.device("cpu")
+    content_sample_rate = 16000
+
+    class _Cfg:
+        top_p, top_k, temperature, length_penalty, repetition_penalty = 0.85, 1, 0.85, 1.0, 2.0
+
+        class audio:
+            sample_rate = 24000
+    config = _Cfg()
+
+    class _Extractor:
+        @staticmethod
+        def extract_content_features(wav):                               # [B,T] -> [B, T50, 4]
+            t50 = (wav.shape[-1] - 400) // 320 + 1
+            frames = wav[:, :t50 * 320].reshape(wav.shape[0], t50, 320)
+            return torch.stack([frames.mean(-1), frames.amax(-1), frames.amin(-1), frames[..., 0]], -1)
+
+    class _Dvae:
+        @staticmethod
+        def get_codebook_indices(x):                                     # [B,4,T50] -> int64 [B, ceil(T50 / 4)]
+            tc = -(-x.shape[-1] // 4)
+            v = torch.nn.functional.pad(x, (0, tc * 4 - x.shape[-1])).reshape(x.shape[0], 4, tc, 4).sum((1, 3))
+            return (v * 1e4).round().long().abs() % 256
+
+    class _Gpt:
+        stop_audio_token, max_gen_mel_tokens = 1025, 12
+        calls = []
+
+        def generate(self, cond, codes, **kw):
+            self.calls.append(tuple(codes.shape))
+            n = 5 + codes.shape[1] % 6
+            base = (codes.sum(1, keepdim=True) + (cond[0].sum() * 1000).long()) % 1000
+            return (base + torch.arange(n)[None, :]) % 1024
+
+    content_extractor, content_dvae = _Extractor(), _Dvae()
+
+    def __init__(self):
+        self.gpt = self._Gpt()
+        self.gpt.calls = []
+
+    def get_gpt_cond_latents(self, audio, sr):
+        return audio[:, :64].reshape(1, 32, 2)
+
+
+def _offline_job():
+    lens = [160000, 96000, 230000, 160000, 40000, 96000, 160000]     # 10 s, 6 s, 14.4 s (3 segments), ..., 2.5 s
+    srcs = [synth.synth_audio(900 + i, "src", n) for i, n in enumerate(lens)]
+    return srcs, synth.synth_audio(7, "ref", 72000)
+
+
+def _offline_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from genvc_amd.parallel_offline import convert_offline
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    srcs, ref = _offline_job()
+    m = _StubModel()
+    out = convert_offline(m, srcs, ref, seg_len=6.0, micro_batch=2, rank=rank, world=world)
+    q.put((rank, out.numpy(), len(m.gpt.calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_convert_offline_world2_unequal_lengths():
+    """the offline driver itself at world size 2 (gloo): length-sorted round-robin sharding of utterances of different lengths,
+    micro-batches that share a call per (segment, length), ONE all_gather -- every rank ends with the world-1 result"""
+    import torch.multiprocessing as mp
+    from genvc_amd.parallel_offline import convert_offline, plan
+    srcs, ref = _offline_job()
+    lens = [int(s.shape[-1]) for s in srcs]
+    assert plan(lens, 0, 2) == [2, 3, 1, 4] and plan(lens, 1, 2) == [0, 6, 5]        # longest first, dealt round-robin
+    m1 = _StubModel()
+    one = convert_offline(m1, srcs, ref, seg_len=6.0, micro_batch=2, rank=0, world=1)
+    assert one.shape == (7, 3, 12) and one.dtype == torch.int32
+    # per utterance == converting it alone (no batch-mate leaks into a row); absent segments are all stop tokens
+    for i, s in enumerate(srcs):
+        alone = convert_offline(_StubModel(), [s], ref, seg_len=6.0, micro_batch=1)
+        assert torch.equal(alone[0], one[i, :alone.shape[1]])
+        assert bool((one[i, alone.shape[1]:] == 1025).all())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_offline_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = {r: (o, n) for r, o, n in (q.get(timeout=180) for _ in range(2))}
+    [p.join(timeout=60) for p in ps]
+    for r in range(2):
+        assert np.array_equal(res[r][0], one.numpy())
+    assert res[0][1] + res[1][1] <= len(m1.gpt.calls) + 3       # sharding does not multiply the generate calls
