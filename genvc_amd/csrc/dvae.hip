@@ -87,8 +87,18 @@ __global__ __launch_bounds__(kVqThreads) void k_vq_argmin(const float* x, const 
     const int g = tid >> 8, jj = tid & 255;
     const int i0 = g * (dim / 4), i1 = g == 3 ? dim : (g + 1) * (dim / 4);
     for (int j = jj; j < n_embed; j += 256) {
+        // 16 codebook loads in flight per thread (the rolled loop waited for every load: 50 us for 13 frames); the sum keeps
+        // the element order i0, i0 + 1, ... of the plain loop
         float dot = 0.f;
-        for (int i = i0; i < i1; ++i) dot = fmaf(xs[i], embed[(size_t)i * n_embed + j], dot);
+        int i = i0;
+        for (; i + 16 <= i1; i += 16) {
+            float e[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e[u] = embed[(size_t)(i + u) * n_embed + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dot = fmaf(xs[i + u], e[u], dot);
+        }
+        for (; i < i1; ++i) dot = fmaf(xs[i], embed[(size_t)i * n_embed + j], dot);
         pd[g * n_embed + j] = dot;
     }
     __syncthreads();

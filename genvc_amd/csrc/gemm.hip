@@ -323,8 +323,10 @@ __global__ __launch_bounds__(64) void k_ln_sum_rows_t(const float* x_in, float* 
 
 int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* part, int SK, const float* bias, int rows, int d,
                        const float* ln_w, const float* ln_b, int a_fm16, hipStream_t s) {
-    GVC_REQUIRE((d == 1024 || d == 256) && SK >= 0 && SK <= 8, GVC_ERR_UNSUPPORTED, "ln_sum_rows: d=%d SK=%d unsupported", d, SK);
+    GVC_REQUIRE(d % 256 == 0 && d >= 256 && d <= 1024 && SK >= 0 && SK <= 8, GVC_ERR_UNSUPPORTED, "ln_sum_rows: d=%d SK=%d unsupported", d, SK);
     if (d == 1024) hipLaunchKernelGGL(k_ln_sum_rows_t<4>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
+    else if (d == 768) hipLaunchKernelGGL(k_ln_sum_rows_t<3>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
+    else if (d == 512) hipLaunchKernelGGL(k_ln_sum_rows_t<2>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
     else hipLaunchKernelGGL(k_ln_sum_rows_t<1>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
@@ -404,14 +406,17 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
 }
 
 int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
-    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && (G.K == 1024 || G.K == 256), GVC_ERR_ARG,
+    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && G.K % 256 == 0 && G.K >= 256 && G.K <= 1024, GVC_ERR_ARG,
                 "skinny gemm + LN: unsupported shape M=%d N=%d K=%d", G.M, G.N, G.K);
     G.SK = 1;
     const size_t lds = ((size_t)16 * G.K + 8 * 256) * sizeof(float);
-    if (G.K == 1024 && G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny_ln<4, 1>), dim3(G.N / 16), dim3(512), lds, s, G, P);
-    else if (G.K == 1024) hipLaunchKernelGGL((k_gemm_skinny_ln<4, 0>), dim3(G.N / 16), dim3(512), lds, s, G, P);
-    else if (G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny_ln<1, 1>), dim3(G.N / 16), dim3(512), lds, s, G, P);
-    else hipLaunchKernelGGL((k_gemm_skinny_ln<1, 0>), dim3(G.N / 16), dim3(512), lds, s, G, P);
+#define GVC_SKINNY_LN(nv)                                                                                                 \
+    if (G.K == 256 * nv) {                                                                                                \
+        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny_ln<nv, 1>), dim3(G.N / 16), dim3(512), lds, s, G, P);             \
+        else hipLaunchKernelGGL((k_gemm_skinny_ln<nv, 0>), dim3(G.N / 16), dim3(512), lds, s, G, P);                      \
+    }
+    GVC_SKINNY_LN(1) GVC_SKINNY_LN(2) GVC_SKINNY_LN(3) GVC_SKINNY_LN(4)
+#undef GVC_SKINNY_LN
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }

@@ -196,7 +196,6 @@ struct GptLayer {
 struct gvc_gpt {
     gvc_gpt_dims dm;
     int hd = 0, n_cu = 256;
-    int prefetch = 0;                 // experimental L2 warm-up of the next launch's weights (GVC_PREFETCH=1)
     float* wbase = nullptr;           // one allocation for all weights
     float* wfm = nullptr;             // FM16 copies of the four per-layer matrices (prefill path)
     unsigned short* wh = nullptr;     // bf16 copies of the streamed matrices (weight_dtype = 1)
@@ -213,10 +212,7 @@ struct gvc_gpt {
     long long work_cap = 0;
     float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
     int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
-    int fuse_mlp = 0;                             // GVC_FUSE_MLP=1: c_fc + in-kernel exchange + mlp c_proj in ONE launch (measured: no faster)
-    unsigned long long* seam_gran = nullptr;      // [4d] {tag,value} granules of the in-kernel hidden-unit exchange
-    unsigned* seam_epoch = nullptr;               // launch counter of that exchange (device)
-    int* seam_err_host = nullptr;                 // pinned, device-visible: set when an in-kernel exchange timed out
+    int* seam_err_host = nullptr;                 // pinned, device-visible: a timed-out hand-off of the one-launch step / a full KV cache
     int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
@@ -233,16 +229,6 @@ struct gvc_gpt {
     std::map<int, hipGraphExec_t> graphs;   // 2*B + fused -> step graph
     int prof_only = -1;               // gvc_gpt_time_kernel(): launch only this kernel class
     int prof_skip_one = -1;           // ... or every class except this one
-    // step-long prefetcher (graph path only)
-    int use_prefetcher = 0;           // measured slower on MI355X; GVC_PREFETCHER=1 enables
-    PrefetchEntry* sched = nullptr;
-    int n_sched = 0;
-    int32_t* prog = nullptr;          // progress counter of the running step
-    int32_t* prog_active = nullptr;   // set while a step graph is being captured
-    int pf_mask = 15;                 // which operands the prefetcher pulls (1 proj, 2 fc, 4 mlp proj, 8 qkv)
-    int prog_base = 0;                // value of the counter at the start of the next step (host mirror)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* dbg = nullptr; // GVC_DEBUG_STAMPS: [launch][8] in-kernel timestamps of the eager decode step
     int dbg_n = 0;
     // one-launch decode step (persist_kernel.h), one stream
@@ -267,9 +253,10 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     const gvc_gpt_dims& D = *dims;
     GVC_REQUIRE(D.n_layer > 0 && D.n_head > 0 && D.d_model % D.n_head == 0, GVC_ERR_ARG, "bad GPT dims");
     const int hd = D.d_model / D.n_head;
-    GVC_REQUIRE(D.d_model == 256 || D.d_model == 1024, GVC_ERR_UNSUPPORTED,
-                "d_model %d unsupported (kernels instantiated for 256 and 1024)", D.d_model);
-    GVC_REQUIRE(hd == 64 || hd == 256, GVC_ERR_UNSUPPORTED, "head_dim %d unsupported (64 or 256)", hd);
+    // the decode GEMVs keep a whole residual row in one wave (d / 256 float4 per lane): d = 256, 512, 768 or 1024
+    GVC_REQUIRE(D.d_model % 256 == 0 && D.d_model >= 256 && D.d_model <= 1024, GVC_ERR_UNSUPPORTED,
+                "d_model %d unsupported (a multiple of 256 up to 1024)", D.d_model);
+    GVC_REQUIRE(hd == 64 || hd == 128 || hd == 256, GVC_ERR_UNSUPPORTED, "head_dim %d unsupported (64, 128 or 256)", hd);
     GVC_REQUIRE(D.max_slots >= 1 && D.max_slots <= 64, GVC_ERR_ARG, "max_slots must be in [1,64]");
     GVC_REQUIRE(D.max_rows >= D.max_slots, GVC_ERR_ARG, "max_rows must be >= max_slots");
     auto* c = new gvc_gpt();
@@ -280,7 +267,6 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipGetDevice(&dev));
     GVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (getenv("GVC_PREFETCH")) c->prefetch = atoi(getenv("GVC_PREFETCH"));
 
     const size_t d = D.d_model, L = D.n_layer, V = D.vocab;
     const size_t per_layer = 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d;
@@ -351,21 +337,10 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipMalloc((void**)&c->gen_call, sizeof(GenCall)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     if ((rc = gemv_init())) { gvc_gpt_destroy(c); return rc; }
-    if (getenv("GVC_PREFETCHER")) c->use_prefetcher = atoi(getenv("GVC_PREFETCHER"));
-    if (getenv("GVC_PF_MASK")) c->pf_mask = atoi(getenv("GVC_PF_MASK"));
     if (getenv("GVC_FUSE_ATTN")) c->fuse_decode = atoi(getenv("GVC_FUSE_ATTN"));
-    if (getenv("GVC_FUSE_MLP")) c->fuse_mlp = atoi(getenv("GVC_FUSE_MLP"));
-    GVC_CHECK_HIP(hipMalloc((void**)&c->seam_gran, (size_t)4 * d * sizeof(unsigned long long) + 64));
-    GVC_CHECK_HIP(hipMemset(c->seam_gran, 0, (size_t)4 * d * sizeof(unsigned long long) + 64));
-    c->seam_epoch = reinterpret_cast<unsigned*>(c->seam_gran + 4 * d);
     GVC_CHECK_HIP(hipHostMalloc((void**)&c->seam_err_host, sizeof(int), hipHostMallocMapped));
     *c->seam_err_host = 0;
     GVC_CHECK_HIP(hipHostGetDevicePointer((void**)&c->seam_err_dev, c->seam_err_host, 0));
-    GVC_CHECK_HIP(hipMalloc((void**)&c->prog, sizeof(int32_t)));
-    GVC_CHECK_HIP(hipMemset(c->prog, 0, sizeof(int32_t)));
-    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (getenv("GVC_PERSIST")) c->persist = atoi(getenv("GVC_PERSIST"));
     if (getenv("GVC_DEBUG_STAMPS")) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->dbg, 4096 * 8 * sizeof(unsigned long long)));
@@ -379,12 +354,6 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (!c) return GVC_OK;
     for (auto& kvp : c->graphs) hipGraphExecDestroy(kvp.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
-    if (c->side_stream) hipStreamDestroy(c->side_stream);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->sched) hipFree(c->sched);
-    if (c->prog) hipFree(c->prog);
-    if (c->seam_gran) hipFree(c->seam_gran);
     if (c->xalt) hipFree(c->xalt);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
     for (void* p : {(void*)c->p_layers, (void*)c->p_gran, (void*)c->p_epoch, (void*)c->p_dbg})
@@ -484,10 +453,12 @@ extern "C" int gvc_gpt_missing_weights(gvc_gpt* c) {
 struct GemvGeom { int NI, ksplit, wpb, grid; };
 
 // launch geometry of a decode GEMV over Wt[N][K]: one wave per (row, 1024-input segment); about one
-// workgroup per CU, two when that would need more than 12 compute waves (+1 prefetcher wave each)
+// workgroup per CU, two when that would need more than 12 compute waves
 static int gemv_geom(const gvc_gpt* c, int N, int K, GemvGeom* g) {
-    g->NI = (K < 1024 ? K : 1024) / 256;
-    GVC_REQUIRE(g->NI == 1 || g->NI == 4, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
+    // a wave owns a segment of NI * 256 inputs: the whole row when K <= 1024, else the largest NI <= 4 that divides K / 256
+    const int k256 = K / 256;
+    g->NI = k256 <= 4 ? k256 : (k256 % 4 == 0 ? 4 : (k256 % 3 == 0 ? 3 : (k256 % 2 == 0 ? 2 : 1)));
+    GVC_REQUIRE(K % 256 == 0 && g->NI >= 1, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
     g->ksplit = K / (g->NI * 256);
     GVC_REQUIRE(g->ksplit * g->NI * 256 == K && g->ksplit <= 8, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
     const int items = N * g->ksplit;
@@ -501,21 +472,6 @@ static int gemv_geom(const gvc_gpt* c, int N, int K, GemvGeom* g) {
     g->wpb = wpb;
     g->grid = cdiv(items, wpb);
     return GVC_OK;
-}
-
-static Prefetch prefetch_of(const gvc_gpt* c, const float* Wt, int N, int K) {
-    Prefetch p;
-    p.base = nullptr; p.chunk_bytes = 0; p.n_chunks = 0;
-    GemvGeom g;
-    if (gemv_geom(c, N, K, &g) == GVC_OK) {
-        p.base = (const char*)Wt;
-        p.chunk_bytes = g.wpb * g.NI * 256 * (int)sizeof(float);
-        p.n_chunks = g.grid;
-        // the last workgroup may own fewer rows: clamp so no byte beyond the matrix is touched
-        const long long total = (long long)N * K * (long long)sizeof(float);
-        while (p.n_chunks > 0 && (long long)p.n_chunks * p.chunk_bytes > total) --p.n_chunks;
-    }
-    return p;
 }
 
 template <int PRO, int EPI>
@@ -535,7 +491,7 @@ static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
     const int BT = B <= 1 ? 1 : (B <= 2 ? 2 : (B <= 4 ? 4 : 8));
     const int grid = g.grid;
     const int wpb = g.wpb;
-    const int nthreads = (wpb + (A.pf.base ? 1 : 0)) * 64;
+    const int nthreads = wpb * 64;
     const size_t lds = ((size_t)BT * A.K + (size_t)wpb * BT) * sizeof(float);
 #define GVC_GEMV_CASE(bt, ni)                                                    \
     if (BT == bt && NI == ni) {                                                  \
@@ -544,8 +500,10 @@ static int launch_gemv(gvc_gpt* c, GemvArgs A, int B, hipStream_t s) {
         GVC_LAUNCH_CHECK();                                                      \
         return GVC_OK;                                                           \
     }
-    GVC_GEMV_CASE(1, 1) GVC_GEMV_CASE(1, 4) GVC_GEMV_CASE(2, 1) GVC_GEMV_CASE(2, 4)
-    GVC_GEMV_CASE(4, 1) GVC_GEMV_CASE(4, 4) GVC_GEMV_CASE(8, 1) GVC_GEMV_CASE(8, 4)
+    GVC_GEMV_CASE(1, 1) GVC_GEMV_CASE(1, 2) GVC_GEMV_CASE(1, 3) GVC_GEMV_CASE(1, 4)
+    GVC_GEMV_CASE(2, 1) GVC_GEMV_CASE(2, 2) GVC_GEMV_CASE(2, 3) GVC_GEMV_CASE(2, 4)
+    GVC_GEMV_CASE(4, 1) GVC_GEMV_CASE(4, 2) GVC_GEMV_CASE(4, 3) GVC_GEMV_CASE(4, 4)
+    GVC_GEMV_CASE(8, 1) GVC_GEMV_CASE(8, 2) GVC_GEMV_CASE(8, 3) GVC_GEMV_CASE(8, 4)
 #undef GVC_GEMV_CASE
     set_error("gemv: no instantiation for BT=%d NI=%d", BT, NI);
     return GVC_ERR_UNSUPPORTED;
@@ -560,8 +518,10 @@ static int gemv_allow_big_lds() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));            \
     GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_gemv<bt, ni, PRO, EPI, 1>,                            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-    GVC_GEMV_ATTR(1, 1) GVC_GEMV_ATTR(1, 4) GVC_GEMV_ATTR(2, 1) GVC_GEMV_ATTR(2, 4)
-    GVC_GEMV_ATTR(4, 1) GVC_GEMV_ATTR(4, 4) GVC_GEMV_ATTR(8, 1) GVC_GEMV_ATTR(8, 4)
+    GVC_GEMV_ATTR(1, 1) GVC_GEMV_ATTR(1, 2) GVC_GEMV_ATTR(1, 3) GVC_GEMV_ATTR(1, 4)
+    GVC_GEMV_ATTR(2, 1) GVC_GEMV_ATTR(2, 2) GVC_GEMV_ATTR(2, 3) GVC_GEMV_ATTR(2, 4)
+    GVC_GEMV_ATTR(4, 1) GVC_GEMV_ATTR(4, 2) GVC_GEMV_ATTR(4, 3) GVC_GEMV_ATTR(4, 4)
+    GVC_GEMV_ATTR(8, 1) GVC_GEMV_ATTR(8, 2) GVC_GEMV_ATTR(8, 3) GVC_GEMV_ATTR(8, 4)
 #undef GVC_GEMV_ATTR
     return GVC_OK;
 }
@@ -596,7 +556,6 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
     A.st = c->st;
     A.mel_emb = c->mel_emb;
     A.mel_pos_tab = c->mel_pos;
-    A.prog = c->prog_active;
     A.kv_bf16 = c->kv_bf16;
     A.err = c->seam_err_dev;
     return A;
@@ -618,7 +577,6 @@ static AttnArgs gpt_attn_args(gvc_gpt* c, int layer, const int32_t* slots) {
     T.slots = slots;
     T.causal = 1;
     T.scale = 1.0f / sqrtf((float)c->hd);
-    T.prog = c->prog_active;
     return T;
 }
 
@@ -634,12 +592,6 @@ static bool fused_ok(const gvc_gpt* c, int B, int max_keys) {
     return c->fuse_decode && B == 1 && c->hd == 256 && c->dm.d_model % 16 == 0 && max_keys <= 8 * kFusedMaxKeys;
 }
 
-// one launch for the MLP block: needs every workgroup of the launch resident at once (d/4 workgroups of 1024 threads)
-static bool mlp_fused_ok(const gvc_gpt* c) {
-    const int d = c->dm.d_model;
-    return c->fuse_mlp && !c->bf16 && (d == 1024 || d == 256) && c->dm.n_head <= 16 && d / 4 <= c->n_cu;
-}
-
 // ---------------------------------------------------------------------------------------------
 // one-launch decode step (persist_kernel.h)
 // ---------------------------------------------------------------------------------------------
@@ -649,10 +601,10 @@ static int persist_set_attr(size_t lds) {
     return GVC_OK;
 }
 
-// one stream, fp32 weights and cache, d in {256, 512, 1024}, head_dim in {64, 128, 256}, a full MI355X (one workgroup per CU)
+// one stream, fp32 weights and cache, a full MI355X (one workgroup per CU)
 static bool persist_ok(const gvc_gpt* c, int B) {
     const int d = c->dm.d_model;
-    return c->persist && B == 1 && !c->bf16 && c->n_cu >= kPG && (d == 256 || d == 512 || d == 1024) &&
+    return c->persist && B == 1 && !c->bf16 && c->n_cu >= kPG && d % 256 == 0 && d <= 1024 &&
            (c->hd == 64 || c->hd == 128 || c->hd == 256) && c->dm.n_layer < 500;
 }
 
@@ -685,7 +637,8 @@ static int persist_prepare(gvc_gpt* c) {
     while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > 160 * 1024) c->p_ring_slots >>= 1;
     c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
     int rc;
-    if ((rc = persist_set_attr<1>(c->p_lds)) || (rc = persist_set_attr<2>(c->p_lds)) || (rc = persist_set_attr<4>(c->p_lds))) return rc;
+    if ((rc = persist_set_attr<1>(c->p_lds)) || (rc = persist_set_attr<2>(c->p_lds)) || (rc = persist_set_attr<3>(c->p_lds)) ||
+        (rc = persist_set_attr<4>(c->p_lds))) return rc;
     PersistLayer* dev = nullptr;
     GVC_CHECK_HIP(hipMalloc((void**)&dev, L * sizeof(PersistLayer)));
     GVC_CHECK_HIP(hipMemcpy(dev, t.data(), L * sizeof(PersistLayer), hipMemcpyHostToDevice));
@@ -707,6 +660,7 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.dbg = c->p_dbg;
     const int nd = c->dm.d_model / 256;
     if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
+    else if (nd == 3) hipLaunchKernelGGL((k_decode_persist<3>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
     else if (nd == 2) hipLaunchKernelGGL((k_decode_persist<2>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
     else hipLaunchKernelGGL((k_decode_persist<1>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
     GVC_LAUNCH_CHECK();
@@ -736,26 +690,11 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
             memset(&F, 0, sizeof(F));
             F.q = qb; F.kcache = A.kcache; F.vcache = A.vcache; F.slots = slots; F.seq_len = c->st.seq_len;
             F.max_seq = c->dm.max_seq; F.n_head = c->dm.n_head; F.d = d; F.scale = 1.0f / sqrtf((float)c->hd);
-            F.Wp = ly.proj_w; F.part2 = c->part2 + (size_t)row0 * c->dm.n_head * d; F.prog = c->prog_active;
+            F.Wp = ly.proj_w; F.part2 = c->part2 + (size_t)row0 * c->dm.n_head * d;
             if (!prof_skip(c, 1)) {
                 if (c->kv_bf16) hipLaunchKernelGGL((k_attn_proj<256, 1>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
                 else hipLaunchKernelGGL((k_attn_proj<256, 0>), dim3(d / 16, c->dm.n_head), dim3(512), 0, s, F);
                 GVC_LAUNCH_CHECK();
-            }
-            if (mlp_fused_ok(c)) {
-                // [sum partials, LN2, c_fc, gelu] -> in-kernel exchange of the hidden units -> [mlp c_proj, residual]: one launch
-                MlpArgs M;
-                memset(&M, 0, sizeof(M));
-                M.x = c->x + (size_t)row0 * d; M.part2 = F.part2; M.pbias = ly.proj_b; M.ln_w = ly.ln2_w; M.ln_b = ly.ln2_b;
-                M.Wfc = ly.fc_w; M.bfc = ly.fc_b; M.Wp2 = ly.p2_w; M.bp2 = ly.p2_b; M.d = d; M.n_head = c->dm.n_head;
-                M.gran = c->seam_gran; M.epoch = c->seam_epoch; M.err = c->seam_err_dev; M.prog = c->prog_active;
-                if (c->dbg && c->dbg_n < 4096) M.dbg = c->dbg + 8 * (size_t)(c->dbg_n++);
-                if (!prof_skip(c, 3)) {
-                    if (d == 1024) hipLaunchKernelGGL((k_mlp_fused<8>), dim3(d / 4), dim3(1024), 0, s, M);
-                    else hipLaunchKernelGGL((k_mlp_fused<2>), dim3(d / 4), dim3(1024), 0, s, M);
-                    GVC_LAUNCH_CHECK();
-                }
-                continue;
             }
             A = base_args(c, slots, row0);
             A.Wt = ly.fc_w; A.Wt16 = ly.fc_h; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
@@ -768,31 +707,24 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
         }
         AttnArgs T = gpt_attn_args(c, l, slots);
         T.q = qb; T.T = 1; T.base_len = c->st.seq_len; T.out = pb;
-        if (c->prefetch) T.pf = prefetch_of(c, ly.proj_w, d, d);
         if (!prof_skip(c, 1) && (rc = launch_attention(c, T, kAttnChunks, B, false, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.proj_w; A.Wt16 = ly.proj_h; A.bias = ly.proj_b; A.N = d; A.K = d; A.in = pb;
-        if (c->prefetch) A.pf = prefetch_of(c, ly.fc_w, 4 * d, d);
         if (!prof_skip(c, 2) && (rc = launch_gemv<PRO_MERGE, EPI_RESID>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.fc_w; A.Wt16 = ly.fc_h; A.bias = ly.fc_b; A.N = 4 * d; A.K = d; A.ln_w = ly.ln2_w; A.ln_b = ly.ln2_b; A.out = hb;
-        if (c->prefetch) A.pf = prefetch_of(c, ly.p2_w, d, 4 * d);
         if (!prof_skip(c, 3) && (rc = launch_gemv<PRO_LN, EPI_GELU>(c, A, B, s))) return rc;
 
         A = base_args(c, slots, row0);
         A.Wt = ly.p2_w; A.Wt16 = ly.p2_h; A.bias = ly.p2_b; A.N = d; A.K = 4 * d; A.in = hb;
-        if (c->prefetch)
-            A.pf = l + 1 < c->dm.n_layer ? prefetch_of(c, c->layers[l + 1].qkv_w, 3 * d, d)
-                                         : prefetch_of(c, c->head_w, c->dm.vocab, d);
         if (!prof_skip(c, 4) && (rc = launch_gemv<PRO_COPY, EPI_RESID>(c, A, B, s))) return rc;
     }
     GemvArgs A = base_args(c, slots, row0);
     A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
     A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
     A.out = logits_out; A.latent_out = latent_out; A.advance = 1; A.step_ctr = step_ctr;
-    if (c->prefetch) A.pf = prefetch_of(c, c->layers[0].qkv_w, 3 * d, d);   // next step's first operand
     if (prof_skip(c, 5)) return GVC_OK;
     return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
 }
@@ -897,8 +829,10 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, w, b, (const float*)nullptr,
                            (const float*)nullptr, skinny ? 1 : 0);
     };
+    int ln_rc = GVC_OK;          // (a lambda cannot return through GVC_REQUIRE: the first failure is kept and returned below)
     auto ln_sum = [&](const float* part, const float* bias, const float* w, const float* b) {
-        (void)launch_ln_sum_rows(c->x, c->x, c->a, part, SKP, bias, rows, d, w, b, 1, s);
+        const int r = launch_ln_sum_rows(c->x, c->x, c->a, part, SKP, bias, rows, d, w, b, 1, s);
+        if (ln_rc == GVC_OK) ln_rc = r;
     };
     // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
@@ -1000,7 +934,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         ln_sum(part_p2, c->layers[c->dm.n_layer - 1].p2_b, nullptr, nullptr);
         GVC_LAUNCH_CHECK();
     }
-    return GVC_OK;
+    return ln_rc;
 }
 
 extern "C" int gvc_gpt_prefill(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
@@ -1075,43 +1009,10 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
 // ---------------------------------------------------------------------------------------------
 // generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
 // ---------------------------------------------------------------------------------------------
-// prefetch schedule of one decode step.  Launch numbering inside a step graph (the progress counter):
-// 0 = k_sample is not counted; layer l: 5l+1 c_attn, 5l+2 attention, 5l+3 attn c_proj, 5l+4 c_fc, 5l+5 mlp c_proj;
-// 5L+1 head.  Each operand is requested one launch ahead of its consumer (two for the small attn c_proj),
-// so at most ~2 operands are in flight / resident in the 32 MB of L2.
-static int build_prefetch_schedule(gvc_gpt* c) {
-    if (c->sched) return GVC_OK;
-    const int L = c->dm.n_layer, d = c->dm.d_model;
-    std::vector<PrefetchEntry> e;
-    auto add = [&](int trig, const float* w, int N, int K) {
-        PrefetchEntry pe;
-        pe.trigger = trig;
-        pe.pf = prefetch_of(c, w, N, K);
-        if (pe.pf.base) e.push_back(pe);
-    };
-    for (int l = 0; l < L; ++l) {
-        const GptLayer& ly = c->layers[l];
-        if (c->pf_mask & 1) add(5 * l + 1, ly.proj_w, d, d);            // while c_attn runs
-        if (c->pf_mask & 2) add(5 * l + 2, ly.fc_w, 4 * d, d);          // while attention runs
-        if (c->pf_mask & 4) add(5 * l + 4, ly.p2_w, d, 4 * d);          // while c_fc runs
-        if (!(c->pf_mask & 8)) continue;
-        if (l + 1 < L) add(5 * l + 5, c->layers[l + 1].qkv_w, 3 * d, d);   // while mlp c_proj runs
-        else add(5 * l + 5, c->head_w, c->dm.vocab, d);
-    }
-    if (c->pf_mask & 8) add(5 * L + 1, c->layers[0].qkv_w, 3 * d, d);   // while the head runs: first operand of the next step
-    GVC_CHECK_HIP(hipMalloc((void**)&c->sched, e.size() * sizeof(PrefetchEntry)));
-    GVC_CHECK_HIP(hipMemcpy(c->sched, e.data(), e.size() * sizeof(PrefetchEntry), hipMemcpyHostToDevice));
-    c->n_sched = (int)e.size();
-    return GVC_OK;
-}
-
 static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) {
     hipStream_t cs = c->cap_stream;
     int rc = GVC_OK;
-    const bool pf = c->use_prefetcher && B <= 8;
-    if (pf && (rc = build_prefetch_schedule(c))) return rc;
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-    if (pf) c->prog_active = c->prog;        // every launch of the step bumps the progress counter
     rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
     if (rc == GVC_OK && persist_ok(c, B))
         rc = launch_persist(c, c->gen_call->slots, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
@@ -1124,7 +1025,6 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) 
         rc = decode_group(c, c->gen_call->slots + g, Bg, g, c->tok_buf + g, c->logits + (size_t)g * c->dm.vocab,
                           c->latent + (size_t)g * c->dm.d_model, last ? c->step_ctr : nullptr, cs, fused);
     }
-    c->prog_active = nullptr;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &graph);
     if (rc != GVC_OK) {
@@ -1171,19 +1071,7 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
         if ((rc = build_step_graph(c, B, fused, &ge))) return rc;
         it = c->graphs.emplace(key, ge).first;
     }
-    // hipGraph branches are serialised on this runtime, so the prefetcher is NOT a graph node: one launch per
-    // step on a side stream runs beside the step graph and follows it through the monotone progress counter
-    const bool pf = c->use_prefetcher && B <= 8 && c->sched;
-    const int per_step = 5 * c->dm.n_layer + 1;
-    for (int i = 0; i < n_steps; ++i) {
-        if (pf) {
-            static const int wgs = getenv("GVC_PF_WGS") ? atoi(getenv("GVC_PF_WGS")) : c->n_cu;
-            hipLaunchKernelGGL(k_step_prefetcher, dim3(wgs), dim3(64), 0, c->side_stream, c->sched, c->n_sched,
-                               c->prog, c->prog_base, 20000, c->use_prefetcher == 2 ? 0 : 1);
-            c->prog_base += per_step;
-        }
-        GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
-    }
+    for (int i = 0; i < n_steps; ++i) GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 1);
     GVC_LAUNCH_CHECK();

@@ -18,13 +18,6 @@ struct GptState {                // device-resident step state, one entry per sl
     int32_t* mel_pos;            // index into mel_pos_embedding of the next decode input
 };
 
-// see prefetch_wave() below
-struct Prefetch {
-    const char* base;    // null: nothing to prefetch
-    int chunk_bytes;     // bytes read by one workgroup of the next launch (contiguous)
-    int n_chunks;
-};
-
 enum Prologue { PRO_LN = 0, PRO_MERGE = 1, PRO_COPY = 2, PRO_LN2X = 3, PRO_LN_SUM = 4 };
 enum Epilogue { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2, EPI_LOGITS = 3 };
 
@@ -58,9 +51,7 @@ struct GemvArgs {
     GptState st;
     int advance;                                // EPI_LOGITS: 1 -> seq_len++, mel_pos++ per slot
     int32_t* step_ctr;                          // EPI_LOGITS: nullable, ++ once per launch (generation loop)
-    Prefetch pf;                                // next launch's weights (L2 warm-up by the extra wave)
     unsigned long long* dbg;                    // null, or 8 timestamps (100 MHz wall clock) of this launch
-    int32_t* prog;                              // null, or the step's progress counter (++ when this launch starts)
     // fused attention path (k_attn_proj): PRO_LN_SUM builds x' = x + pbias + sum_h part2[b][h] and stores it to x2;
     // EPI_RESID then reads its residual from xres (= x2) instead of x
     const float* part2; const float* pbias; float* x2; const float* xres;
@@ -78,27 +69,6 @@ struct GemvArgs {
 // vmcnt retires in order, hence the small prologue loads are issued BEFORE the weight stream.
 // HBM-bound: N*K*4 algorithmic bytes per launch.  BT = streams per launch (padded), B live ones.
 // ---------------------------------------------------------------------------------------------
-// Warm the XCD-local L2 with the weights the NEXT kernel will stream.  Executed by one extra wave per
-// workgroup that returns right afterwards: its loads are fire-and-forget (s_endpgm waits for them), so
-// the compute waves' in-order vmcnt never sees them and the kernel overlaps its own latency chain with
-// the next operand's HBM transfer.  Chunk cb is what workgroup cb of the next launch reads; it is
-// fetched by a workgroup with the same index modulo 8 (observed XCD placement; affects speed only).
-__device__ __forceinline__ void prefetch_wave(const Prefetch& P, int lane, int block, int nblocks) {
-    const int r = block & 7;
-    const int nb_r = (nblocks - r + 7) >> 3;            // workgroups of this launch with residue r
-    const int i = block >> 3;
-    // hipcc does not track an asm load: the destination is a register kept live ("+v") up to our own
-    // wait, so it can never be re-used for an address while a load is still in flight
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    f32x4_t sink = {0.f, 0.f, 0.f, 0.f};
-    for (int cb = r + 8 * i; cb < P.n_chunks; cb += 8 * nb_r) {
-        const char* p = P.base + (size_t)cb * P.chunk_bytes;
-        for (int off = lane * 16; off < P.chunk_bytes; off += 64 * 16)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p + off) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
-}
-
 // PRO_LN_SUM keeps more loads in flight per lane: it is launched with at most 8 waves (256-VGPR budget)
 // WB = 1: the matrix is streamed from its bf16 copy (Wt16, same [N][K] layout; half the HBM bytes), products and
 // accumulation stay fp32.  Lane l then owns inputs [512j + 8l, +8) of its segment instead of [256i + 4l, +4).
@@ -107,14 +77,8 @@ __global__ __launch_bounds__(PRO == PRO_LN_SUM ? 512 : 1024) void k_gemv(const G
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nwave = A.wpb;                   // compute waves; wave == nwave is the prefetcher
-    if (wave >= nwave) {
-        if (A.pf.base) prefetch_wave(A.pf, lane, blockIdx.x, gridDim.x);
-        return;                                // a terminated wave no longer counts at s_barrier
-    }
+    const int nwave = A.wpb;
     constexpr int KSEG = NI * 256;
-    if (A.prog && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool stamp = A.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
     unsigned long long* dbg = A.dbg + (blockIdx.x == 0 ? 0 : 4);
     if (stamp) dbg[0] = wall_clock64();
@@ -473,8 +437,6 @@ struct AttnArgs {
     float scale;
     float* out;                // DIRECT: [rows][out_stride] ; else partials [rows][heads][chunks][HD+4]
     int out_stride;
-    Prefetch pf;               // next launch's weights, fetched by the 5th wave (blockDim 320)
-    int32_t* prog;             // null, or the step's progress counter (++ when this launch starts)
     int out_fm16;              // DIRECT: write `out` in the FM16 layout of gemm.h (row length out_stride)
 };
 
@@ -496,15 +458,7 @@ __device__ __forceinline__ float4 kv_f4(const uint2& u) {
 }
 
 template <int HD, bool DIRECT, int NW = 4, int KVB = 0>
-__global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const AttnArgs A) {
-    if (NW == 4 && threadIdx.x >= 256) {      // optional prefetcher wave, see prefetch_wave()
-        if (A.pf.base)
-            prefetch_wave(A.pf, threadIdx.x & 63, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
-                          gridDim.x * gridDim.y * gridDim.z);
-        return;
-    }
-    if (A.prog && threadIdx.x == 0 && blockIdx.x + blockIdx.y + blockIdx.z == 0)
-        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__global__ __launch_bounds__(NW * 64) void k_attention(const AttnArgs A) {
     constexpr int LPK = HD / 4;          // lanes per key
     constexpr int KPW = 64 / LPK;        // keys per wave-instruction
     constexpr int NG = NW * KPW;         // softmax states per block
@@ -548,6 +502,7 @@ __global__ __launch_bounds__(NW == 4 ? 320 : NW * 64) void k_attention(const Att
         for (int u = 0; u < U; ++u) {
             float d = dot4(q4, kv_f4(kv[u]));
             if constexpr (LPK == 64) d = wave_sum(d);
+            else if constexpr (LPK == 32) { d = row16_sum(d); d += __shfl_xor(d, 16); }
             else d = row16_sum(d);                         // LPK == 16
             s[u] = (kb + u * NW * KPW < k1) ? d * A.scale : -INFINITY;
         }
@@ -619,7 +574,6 @@ struct AttnProjArgs {
     float scale;
     const float* Wp;           // attn c_proj, row-per-output [d][d]
     float* part2;              // [heads][d] partial projections
-    int32_t* prog;
 };
 
 template <int HD, int KVB = 0>
@@ -629,8 +583,6 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
     __shared__ float l_s[8];
     __shared__ __attribute__((aligned(16))) float o_s[8][HD];
     __shared__ __attribute__((aligned(16))) float o_f[HD];
-    if (A.prog && threadIdx.x == 0 && blockIdx.x + blockIdx.y == 0)
-        __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.y;
     const int slot = A.slots[0];
@@ -700,240 +652,11 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused MLP block of the one-stream decode step: [x' = x + attn c_proj bias + sum_h partials; LN2; c_fc; gelu_new]
-// -> in-kernel all-to-all of the 4d hidden units -> [mlp c_proj; x = x' + ...], ONE launch instead of two.
-//   * grid = d/4 workgroups (one per CU at d = 1024), all co-resident; 8 compute waves + 8 auxiliary waves.
-//   * the compute waves request BOTH weight slices of their workgroup at kernel start (16 hidden rows of c_fc and
-//     4 output rows of c_proj, 64 KiB each at d = 1024), so the c_proj stream runs underneath the c_fc phase and the
-//     exchange; nothing else is ever loaded by them (vmcnt retires in order per wave).
-//   * the auxiliary waves (no weight load outstanding) do the prologue and the exchange: every hidden unit is published
-//     as an 8-byte {tag, value} granule with an agent-scope store and gathered with agent-scope loads (the only
-//     hand-off that crosses XCDs: L2s are not coherent with each other); tag = launch epoch, kept in device memory
-//     and bumped by workgroup 0 at its end, after it has seen every workgroup's granules.
-//   * spins are bounded: a timeout raises *err (checked by the host) instead of hanging the GPU.
-// Workgroup barriers are bare s_barrier + lgkmcnt wait, so they do not drain the weight stream.
-// ---------------------------------------------------------------------------------------------
-struct MlpArgs {
-    float* x;                    // residual row of the stream [d], updated in place
-    const float* part2;          // [heads][d] per-head attention-projection partials (k_attn_proj)
-    const float* pbias;          // attn c_proj bias [d]
-    const float* ln_w; const float* ln_b;
-    const float* Wfc; const float* bfc;      // [4d][d], [4d]
-    const float* Wp2; const float* bp2;      // [d][4d], [d]
-    int d, n_head;
-    unsigned long long* gran;    // [4d] granules
-    unsigned* epoch;             // tag of the last launch that used `gran`
-    int* err;
-    int32_t* prog;
-    unsigned long long* dbg;     // null, or 8 timestamps: workgroup 0 {entry, LN2 ready, published, gathered}, last workgroup the same
-};
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <int NI>        // d = 128 * NI
-__global__ __launch_bounds__(1024) void k_mlp_fused(const MlpArgs A) {
-    constexpr int D = 128 * NI, F = 4 * D, D4 = D / 4;
-    constexpr int WPR1 = D4 / 64;          // waves per c_fc row (K = d)
-    constexpr int WPR2 = D / 64;           // wave-partials per c_proj row (K = 4d): 2 * NI
-    __shared__ __attribute__((aligned(16))) float a_s[D];      // LN2(x')
-    __shared__ __attribute__((aligned(16))) float xp_s[D];     // x'
-    __shared__ __attribute__((aligned(16))) float h_s[F];      // gathered hidden units
-    __shared__ float red1[16][WPR1 > 0 ? WPR1 : 1];
-    __shared__ float red2[4][WPR2];
-    __shared__ float stat1[8], stat2[8];
-    __shared__ unsigned tag_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-    if (wave < 8) {
-        // ---------------- compute waves: weights only ----------------
-        f32x4_nt w1[NI], w2[NI];
-        const f32x4_nt* p1 = reinterpret_cast<const f32x4_nt*>(A.Wfc + (size_t)wg * 16 * D) + tid;
-        const f32x4_nt* p2 = reinterpret_cast<const f32x4_nt*>(A.Wp2 + (size_t)wg * 4 * F) + tid;
-        // epilogue operands first (vmcnt retires in order: nothing may be requested behind the weight stream)
-        const float e_b1 = tid < 16 ? A.bfc[wg * 16 + tid] : 0.f;
-        const float e_b2 = tid < 4 ? A.bp2[wg * 4 + tid] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) w1[i] = __builtin_nontemporal_load(p1 + i * 512);
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();               // b0
-        lds_barrier();               // b0'
-        lds_barrier();               // b1: a_s ready
-        // the c_proj slice is requested only now: asked for at kernel start it doubles the queue in front of the prologue's
-        // small loads (they then return after ~6 us instead of ~2); from here it streams underneath phase 1 and the exchange
-#pragma unroll
-        for (int i = 0; i < NI; ++i) w2[i] = __builtin_nontemporal_load(p2 + i * 512);
-        __builtin_amdgcn_sched_barrier(0);
-        // phase 1: 16 hidden rows of c_fc; float4 f = i*512 + tid sits in row f / D4 at column 4 * (f % D4)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int f = i * 512 + tid;
-            const float4 av = *reinterpret_cast<const float4*>(&a_s[(f % D4) * 4]);
-            float s = fmaf(w1[i].x, av.x, 0.f); s = fmaf(w1[i].y, av.y, s); s = fmaf(w1[i].z, av.z, s); s = fmaf(w1[i].w, av.w, s);
-            s = wave_sum(s);
-            if (lane == 0) red1[(i * 512 + wave * 64) / D4][((i * 512 + wave * 64) % D4) / 64] = s;
-        }
-        lds_barrier();               // b2: row partials ready
-        if (tid < 16) {
-            float v = e_b1;
-#pragma unroll
-            for (int q = 0; q < WPR1; ++q) v += red1[tid][q];
-            v = gelu_new(v);
-            const unsigned tag = tag_s;
-            __hip_atomic_store(A.gran + wg * 16 + tid, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lds_barrier();               // b3: h_s ready
-        // phase 2: 4 output rows of c_proj; float4 f sits in row f / D at column 4 * (f % D) of the 4d inputs
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int f = i * 512 + tid;
-            const float4 hv = *reinterpret_cast<const float4*>(&h_s[(f % D) * 4]);
-            float s = fmaf(w2[i].x, hv.x, 0.f); s = fmaf(w2[i].y, hv.y, s); s = fmaf(w2[i].z, hv.z, s); s = fmaf(w2[i].w, hv.w, s);
-            s = wave_sum(s);
-            if (lane == 0) red2[(i * 512 + wave * 64) / D][((i * 512 + wave * 64) % D) / 64] = s;
-        }
-        lds_barrier();               // b4
-        if (tid < 4) {
-            const int row = wg * 4 + tid;
-            float v = e_b2;
-#pragma unroll
-            for (int q = 0; q < WPR2; ++q) v += red2[tid][q];
-            A.x[row] = xp_s[row] + v;
-        }
-        return;
-    }
-    // ---------------- auxiliary waves: prologue + exchange ----------------
-    const int at = tid - 512;                     // 0..511
-    const int aw = wave - 8;                      // 0..7
-    const bool stamp = A.dbg && at == 0 && (wg == 0 || wg == (int)gridDim.x - 1);
-    unsigned long long* dbg = A.dbg + (wg == 0 ? 0 : 4);
-    if (stamp) dbg[0] = wall_clock64();
-    if (at == 0) {
-        if (A.prog && wg == 0) __hip_atomic_fetch_add(A.prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tag_s = *A.epoch + 1u;
-    }
-    // x' = x + pbias + sum_h part2[h]: thread `at` owns floats [4*at, 4*at+4) when 4*at < D
-    const bool has = at * 4 < D;
-    const int col = at * 4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), g4 = t, c4 = t;
-    if (has) {
-        t = *reinterpret_cast<const float4*>(A.x + col);
-        const float4 pb = *reinterpret_cast<const float4*>(A.pbias + col);
-        g4 = *reinterpret_cast<const float4*>(A.ln_w + col);
-        c4 = *reinterpret_cast<const float4*>(A.ln_b + col);
-        float4 ph[16];
-#pragma unroll
-        for (int h = 0; h < 16; ++h)
-            if (h < A.n_head) ph[h] = *reinterpret_cast<const float4*>(A.part2 + (size_t)h * D + col);
-        t.x += pb.x; t.y += pb.y; t.z += pb.z; t.w += pb.w;
-#pragma unroll
-        for (int h = 0; h < 16; ++h)
-            if (h < A.n_head) { t.x += ph[h].x; t.y += ph[h].y; t.z += ph[h].z; t.w += ph[h].w; }
-        *reinterpret_cast<float4*>(&xp_s[col]) = t;
-    }
-    constexpr int AWV = D / 256;                  // auxiliary waves that hold data (4 at d = 1024, 1 at d = 256)
-    const float inv_d = 1.0f / (float)D;
-    {
-        const float s1 = wave_sum((t.x + t.y) + (t.z + t.w));
-        if (lane == 0) stat1[aw] = s1;
-    }
-    lds_barrier();                   // b0
-    float mean = 0.f;
-#pragma unroll
-    for (int i = 0; i < AWV; ++i) mean += stat1[i];
-    mean *= inv_d;
-    {
-        float s2 = 0.f;
-        if (has) {
-            const float a0 = t.x - mean, a1 = t.y - mean, a2 = t.z - mean, a3 = t.w - mean;
-            s2 = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-        s2 = wave_sum(s2);
-        if (lane == 0) stat2[aw] = s2;
-    }
-    lds_barrier();                   // b0'
-    float var = 0.f;
-#pragma unroll
-    for (int i = 0; i < AWV; ++i) var += stat2[i];
-    const float rstd = 1.0f / sqrtf(var * inv_d + 1e-5f);
-    if (has) {
-        float4 o;
-        o.x = (t.x - mean) * rstd * g4.x + c4.x; o.y = (t.y - mean) * rstd * g4.y + c4.y;
-        o.z = (t.z - mean) * rstd * g4.z + c4.z; o.w = (t.w - mean) * rstd * g4.w + c4.w;
-        *reinterpret_cast<float4*>(&a_s[col]) = o;
-    }
-    lds_barrier();                   // b1
-    if (stamp) dbg[1] = wall_clock64();
-    lds_barrier();                   // b2 (the compute waves publish right after it)
-    if (stamp) dbg[2] = wall_clock64();
-    // gather the 4d hidden units of all workgroups
-    {
-        const unsigned tag = tag_s;
-        int spins = 0;
-        for (int idx = at; idx < F; idx += 512) {
-            unsigned long long g;
-            while (true) {
-                g = __hip_atomic_load(A.gran + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((unsigned)(g >> 32) == tag)) break;
-                if (++spins > 400000) { if (lane == 0) *A.err = 1; break; }      // ~0.1 s: not all workgroups resident?
-                __builtin_amdgcn_s_sleep(1);
-            }
-            h_s[idx] = __uint_as_float((unsigned)g);
-        }
-    }
-    if (stamp) dbg[3] = wall_clock64();
-    lds_barrier();                   // b3
-    lds_barrier();                   // b4
-    // every workgroup has published (this one gathered all of them) and read the epoch long ago: bump it for the next launch
-    if (wg == 0 && at == 0) *A.epoch = tag_s;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Step-long weight prefetcher (one launch per decode step on a side stream, concurrent with the step graph).
-// One single-wave workgroup per CU polls the step's progress counter; when launch number `trigger` has
-// started it pulls the operand of a LATER launch from HBM into its XCD's L2 (chunk cb goes to a workgroup
-// with cb % 8 == its own index % 8, matching the consumer's observed placement), so the consumer's
-// non-temporal weight loads hit L2 and HBM keeps streaming across launch boundaries.  Pure loads: results
-// never depend on it; the spin is bounded.
-// ---------------------------------------------------------------------------------------------
-struct PrefetchEntry {
-    int trigger;            // issue when *prog >= trigger
-    Prefetch pf;
-};
-
-static __global__ __launch_bounds__(64) void k_step_prefetcher(const PrefetchEntry* sched, int n_entries, const int32_t* prog,
-                                                               int base, int max_polls, int fetch) {
-    const int lane = threadIdx.x;
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    f32x4_t sink = {0.f, 0.f, 0.f, 0.f};
-    const int r = blockIdx.x & 7;
-    const int nb_r = (gridDim.x - r + 7) >> 3;
-    const int i = blockIdx.x >> 3;
-    for (int e = 0; e < n_entries; ++e) {
-        const int trig = base + sched[e].trigger;     // the counter is monotone over the steps of a context
-        int polls = 0;
-        while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - trig < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++polls > max_polls) return;        // the step is not progressing: give up quietly
-        }
-        const Prefetch P = sched[e].pf;
-        if (!fetch) continue;
-        for (int cb = r + 8 * i; cb < P.n_chunks; cb += 8 * nb_r) {
-            const char* p = P.base + (size_t)cb * P.chunk_bytes;
-            for (int off = lane * 16; off < P.chunk_bytes; off += 64 * 16)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(p + off) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
-    }
-}
-
 // host launcher shared by the GPT and Perceiver contexts
 static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& T, int chunks, int rows, bool direct,
                                       hipStream_t s, bool wide = false, bool kv_bf16 = false) {
     dim3 grid(chunks, n_head, rows);
-    dim3 block(T.pf.base ? 320 : 256);
+    dim3 block(256);
     if (kv_bf16 && head_dim == 256) {
         if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16, 1>), grid, dim3(1024), 0, s, T);
         else if (direct) hipLaunchKernelGGL((k_attention<256, true, 4, 1>), grid, block, 0, s, T);
@@ -948,8 +671,14 @@ static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& 
     } else if (head_dim == 64) {
         if (direct) hipLaunchKernelGGL((k_attention<64, true>), grid, block, 0, s, T);
         else hipLaunchKernelGGL((k_attention<64, false>), grid, block, 0, s, T);
+    } else if (kv_bf16 && head_dim == 128) {
+        if (direct) hipLaunchKernelGGL((k_attention<128, true, 4, 1>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<128, false, 4, 1>), grid, block, 0, s, T);
+    } else if (head_dim == 128) {
+        if (direct) hipLaunchKernelGGL((k_attention<128, true>), grid, block, 0, s, T);
+        else hipLaunchKernelGGL((k_attention<128, false>), grid, block, 0, s, T);
     } else {
-        set_error("attention: head_dim %d unsupported (64 or 256)", head_dim);
+        set_error("attention: head_dim %d unsupported (64, 128 or 256)", head_dim);
         return GVC_ERR_UNSUPPORTED;
     }
     GVC_LAUNCH_CHECK();

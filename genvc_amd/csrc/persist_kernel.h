@@ -380,7 +380,7 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
 template <int ND>      // d_model = 256 * ND
 __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs A) {
     constexpr int D = 256 * ND;
-    constexpr int KSC = ND >= 2 ? 2 : 1;         // K-split of an attn c_proj row over waves (partial sums = planes of X0)
+    constexpr int KSC = ND % 2 == 0 ? 2 : 1;     // K-split of an attn c_proj row over waves (partial sums = planes of X0)
     constexpr int KSE = 2;                       // K-split of an mlp c_proj row (planes of X1)
     constexpr int NJX = (D + kPCW * 128 - 1) / (kPCW * 128);        // 16-byte loads per lane and plane in a sweep over a d-vector
     extern __shared__ __attribute__((aligned(16))) float smem[];      // (same declaration as k_gemv's)

@@ -10,8 +10,7 @@ built as HIP kernels behind `gvc_hubert_*` (genvc_amd/csrc/hubert.hip).  This fi
     whose `.model` holds the fairseq-named parameters, so a GenVC checkpoint's `content_extractor.model.*` keys load
     with `load_state_dict`.  The reference's `padding_mask = (wav == 0)` (:24) is applied inside `gvc_hubert_forward` with
     fairseq's frame reduction (a frame whose whole chunk of samples is exactly zero is padding: zeroed ahead of the positional
-    conv, excluded as an attention key) -- it matters for the harness's zero-padded tail segment and for digital silence;
-  * `SyntheticContentExtractor`: a cheap deterministic stand-in kept for plumbing tests (NOT ContentVec).
+    conv, excluded as an attention key) -- it matters for the harness's zero-padded tail segment and for digital silence.
 """
 import torch
 from torch import nn
@@ -67,30 +66,6 @@ class ContentvecExtractor(nn.Module):
             self.bind()
         device = next(self.model.parameters()).device
         return self._engine.forward(wavs.to(device=device, dtype=torch.float32).contiguous())
-
-    def forward(self, wavs):
-        return self.extract_content_features(wavs)
-
-
-class SyntheticContentExtractor(nn.Module):
-    def __init__(self, dim=256, seed=0):
-        super().__init__()
-        from .. import synth
-        self.dim = dim
-        # 400-sample receptive field / 320-sample hop of the real conv stack
-        self.register_buffer("proj", synth.uniform(seed, "synthetic_contentvec.proj", (dim, 400), 0.25))
-
-    @property
-    def model(self):
-        """the reference's model_init touches `.content_extractor.model` (model_init.py:29-30)"""
-        return self
-
-    @torch.inference_mode()
-    def extract_content_features(self, wavs):
-        B, T = wavs.shape
-        n = contentvec_frames(T)
-        frames = wavs.unfold(1, 400, 320)[:, :n]                      # [B,n,400]
-        return torch.tanh(frames.to(torch.float32) @ self.proj.t().to(wavs.device) * 8.0)
 
     def forward(self, wavs):
         return self.extract_content_features(wavs)
