@@ -19,7 +19,8 @@
 //     zeroed between steps, the epoch lives in device memory and is bumped by the last workgroup to finish the step.
 // Per layer: A [LN1, c_attn] -> B [attention, split over <= 8 key chunks per head, a few workgroups] ->
 //            C [merge of the chunk partials, attn c_proj, residual] -> D [LN2, c_fc, gelu_new] -> E [mlp c_proj, residual];
-// then the double-LayerNorm head.  Every spin is bounded: on a timeout the workgroup sets *err, and the host raises
+// then the double-LayerNorm head.  Contexts of <= 80 keys (head_dim 256, <= 4 heads) fuse B and C (persist_fused_attn).
+// Every spin is bounded: on a timeout the workgroup sets *err, and the host raises
 // GVC_ERR_STATE on the next call.
 #pragma once
 #include "gpt_kernels.h"
@@ -32,6 +33,7 @@ constexpr int kPThreads = (kPCW + 1) * 64;
 constexpr int kPSlot = 16384;       // bytes per ring slot = one LDS-DMA fill (16 x 1 KiB wave-instructions)
 constexpr int kPMaxChunks = 8;      // key chunks per head
 constexpr int kPU = 4;              // keys per lane group held in registers per pass
+constexpr int kPUF = 10;            // ... in the fused attention + projection phase (short contexts: kPUF * kPCW keys)
 constexpr unsigned kPSpinLimit = 400000;
 // LDS control words
 constexpr int kCtlFilled = 0, kCtlDone = 1, kCtlArrive = 1 + kPCW, kCtlAbort = 2 + kPCW, kCtlWords = 16;
@@ -56,7 +58,7 @@ struct PersistArgs {
     float* latent_out;              // [d]
     int32_t* step_ctr;              // nullable
     int advance;
-    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[2][d] | HH[4d] | X1[2][d]
+    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[4][d] | HH[4d] | X1[2][d]
     unsigned* epoch;                // [0] step epoch, [1] arrival counter of the running step
     int* err;                       // device-visible host word: != 0 after a timeout
     int ring_slots;                 // power of two
@@ -65,7 +67,14 @@ struct PersistArgs {
 };
 
 // granules of the hand-off buffers (host: allocation size)
-static inline size_t persist_granules(int d, int H) { return (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + 2 * d + 4 * d + 2 * d; }
+static inline size_t persist_granules(int d, int H) { return (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + 4 * d + 4 * d + 2 * d; }
+
+// Short contexts of the trained GenVC shape (head_dim 256, <= 4 heads): attention and the attn c_proj run as ONE phase --
+// workgroup (i, h) recomputes head h's attention (<= kPUF * kPCW keys, K/V rows from L2) and multiplies it into its rows of the
+// head's K-slice of c_proj; the per-head partial sums are planes of X0 that D's gather adds.  Four hand-offs per layer instead of five.
+__host__ __device__ static inline bool persist_fused_attn(int n_head, int head_dim, int n_keys) {
+    return head_dim == 256 && n_head <= 4 && (kPG % n_head) == 0 && n_keys <= kPUF * kPCW;
+}
 
 struct PCtx {
     int lane, wave, wg;
@@ -261,8 +270,8 @@ __device__ __forceinline__ float group_sum(float v, int lpk) {
     return v;
 }
 
-// Phase C input: the <= kPMaxChunks key-chunk partials (o, m, l) of the head that owns flat output dims [e, e + 4).  Polls the
-// {m, l} granules of the LAST chunk (sentinel), then reads every chunk and merges the partial softmax states.  NCT >= nchunks
+// Phase C input: the <= kPMaxChunks key-chunk partials (o, m, l) of the head that owns flat output dims [e, e + 4): reads every
+// chunk after polling the {m, l} granules of the LAST chunk (sentinel) and merges the partial softmax states.  NCT >= nchunks
 // is a compile-time bound (registers are statically indexed); slots past nchunks re-read the last chunk with weight 0.
 template <int NCT>
 __device__ __forceinline__ float4 merge_chunks(PCtx& c, __amdgpu_buffer_rsrc_t grs, int iP, int PS, int D, int nchunks, int e, int h,
@@ -313,6 +322,7 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
     constexpr unsigned D = 256 * ND;
     const unsigned rmask = A.ring_slots - 1;
     const int rm = A.vocab / kPG, rem = A.vocab - rm * kPG;
+    const bool fused = persist_fused_attn(A.n_head, A.head_dim, A.st.seq_len[A.slots[0]] + 1);
     unsigned fseq = 0;
     const int n_seg = 4 * A.n_layer + 2;
 #pragma unroll 1
@@ -320,10 +330,15 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
         // segment = this workgroup's rows of one matrix: contiguous in the row-per-output layout
         const float* base;
         unsigned bytes;
+        unsigned kib_stride = 1024;                  // global bytes between consecutive KiB of the segment (contiguous rows)
         if (sgi < 4 * A.n_layer) {
             const PersistLayer& Ly = A.layers[sgi >> 2];
             const int ph = sgi & 3;
             if (ph == 0) { base = Ly.qkv_w + (size_t)c.wg * (3 * ND) * D; bytes = 3 * ND * D * 4; }
+            else if (ph == 1 && fused) {             // rows [i RF, (i+1) RF) x the 1 KiB K-slice of head h: one KiB per row
+                const int h = c.wg % A.n_head, i = c.wg / A.n_head, RF = ND * A.n_head;
+                base = Ly.proj_w + (size_t)i * RF * D + h * 256; bytes = RF * 1024; kib_stride = D * 4;
+            }
             else if (ph == 1) { base = Ly.proj_w + (size_t)c.wg * ND * D; bytes = ND * D * 4; }
             else if (ph == 2) { base = Ly.fc_w + (size_t)c.wg * (4 * ND) * D; bytes = 4 * ND * D * 4; }
             else { base = Ly.p2_w + (size_t)c.wg * ND * (4 * D); bytes = ND * 4 * D * 4; }
@@ -353,18 +368,18 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
             const unsigned n = (min((unsigned)kPSlot, bytes - off)) >> 10;
             const unsigned slot = __builtin_amdgcn_readfirstlane(fseq & rmask);
             char* dst = ring + slot * kPSlot;
-            const char* src = reinterpret_cast<const char*>(base) + off + c.lane * 16;
+            const char* src = reinterpret_cast<const char*>(base) + (size_t)(off >> 10) * kib_stride + c.lane * 16;
             if (n == 16) {           // thinned: at most this fill and the one before it in flight
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * kib_stride),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 lds_st(c.ctl + kCtlFilled, fseq);
             } else {
 #pragma unroll 1
                 for (unsigned i = 0; i < n; ++i)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * kib_stride),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_st(c.ctl + kCtlFilled, fseq + 1);
@@ -416,12 +431,13 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const int pass_keys = kPU * kPCW * kpw;
         const int kc = max(pass_keys, (n_keys + kPMaxChunks - 1) / kPMaxChunks);
         const int nchunks = (n_keys + kc - 1) / kc;
-        const bool is_attn = wg < H * nchunks;
+        const bool fused = persist_fused_attn(H, hd, n_keys);
+        const bool is_attn = !fused && wg < H * nchunks;
         const int ah = wg / nchunks, ac = wg - ah * nchunks;
         const float scale = 1.0f / sqrtf((float)hd);
         const int PS = D + 2 * H;                        // granules per key chunk: o[D] | {m, l}[H]
         // granule indices of the five hand-off buffers inside the allocation
-        const int iQ = 0, iP = 3 * D, iX0 = iP + kPMaxChunks * PS, iH = iX0 + 2 * D, iX1 = iH + 4 * D;
+        const int iQ = 0, iP = 3 * D, iX0 = iP + kPMaxChunks * PS, iH = iX0 + 4 * D, iX1 = iH + 4 * D;
         const __amdgpu_buffer_rsrc_t grs = make_rsrc(A.gran, (unsigned)(iX1 + 2 * D) * 8u);
         const unsigned tbase = ((epoch + 1u) & 0xfffffu) << 12;
         auto tag_of = [&](int l, int p) { return tbase | (unsigned)(l * 8 + p + 1); };
@@ -601,6 +617,116 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 }
                 stamp_at(l, 1, 1);
             }
+            // =================== BC (short contexts): attention of head h + its K-slice of attn c_proj, every workgroup ===================
+            if (fused) {
+                GVC_PHASE_BEGIN();
+                const int fh = wg % H, fi = wg / H, RF = ND * H;        // head, row block, rows of the block
+                const unsigned head_bytes = (unsigned)A.max_seq * 256u * 4u;
+                const __amdgpu_buffer_rsrc_t krs = make_rsrc(Ly.kcache + ((size_t)slot * H + fh) * A.max_seq * 256, head_bytes);
+                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(Ly.vcache + ((size_t)slot * H + fh) * A.max_seq * 256, head_bytes);
+                float4 kr[kPUF], vr[kPUF];
+                {       // cached rows of the whole head (written by earlier launches), requested ahead of the seam: key u * 8 + wave
+                    const int voff = (wave * 256 + lane * 4) * 4;
+#pragma unroll
+                    for (int u = 0; u < kPUF; ++u) {
+                        pu32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                        if (u * kPCW + wave < S) {
+                            kk = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * 1024, 0);
+                            vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * 1024, 0);
+                        }
+                        kr[u] = make_float4(__uint_as_float(kk.x), __uint_as_float(kk.y), __uint_as_float(kk.z), __uint_as_float(kk.w));
+                        vr[u] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
+                    }
+                }
+                const int r0 = wave, r1 = wave + kPCW;                   // this wave's rows of the block (RF <= 16)
+                const float bias0 = fh == 0 && r0 < RF ? Ly.proj_b[fi * RF + r0] : 0.f;
+                const float bias1 = fh == 0 && r1 < RF ? Ly.proj_b[fi * RF + r1] : 0.f;
+                // q_h | k_h | v_h of this step: 768 granules = 384 pairs, ONE 16-byte load per lane of waves 0..5 (a single round trip)
+                if (wave < 6 && !c.dead) {
+                    const int t = 2 * (wave * 64 + lane), sg = t >> 8;
+                    const int off = (iQ + sg * D + fh * 256 + (t & 255)) * 8;
+                    const unsigned tg = tag_of(l, 0);
+                    unsigned spins = 0;
+                    pu32x4 v;
+                    while (true) {
+                        v = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
+                        if (__all(v.y == tg && v.w == tg)) break;
+                        if (spin_fail(c, spins, 200 + l, 3)) break;
+                    }
+                    *reinterpret_cast<float2*>(ascr + t) = make_float2(__uint_as_float(v.x), __uint_as_float(v.z));
+                }
+                cbar(c);
+                stamp_at(l, 1, 0);
+                const float4 q4 = *reinterpret_cast<const float4*>(ascr + lane * 4);
+                float sc[kPUF];
+#pragma unroll
+                for (int u = 0; u < kPUF; ++u) {
+                    if (u * kPCW + wave == S) {                          // the key of this step comes from the gathered granules
+                        kr[u] = *reinterpret_cast<const float4*>(ascr + 256 + lane * 4);
+                        vr[u] = *reinterpret_cast<const float4*>(ascr + 512 + lane * 4);
+                    }
+                    sc[u] = dot4(q4, kr[u]);
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < kPUF; ++u) {
+                    const float dsum = wave_sum(sc[u]);
+                    sc[u] = u * kPCW + wave <= S ? dsum * scale : -INFINITY;
+                    m = fmaxf(m, sc[u]);
+                }
+                float lsum = 0.f;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < kPUF; ++u) {
+                    const float p = __expf(sc[u] - m);                   // (every wave owns at least key `wave` <= S... see below)
+                    lsum += p;
+                    o.x = fmaf(p, vr[u].x, o.x); o.y = fmaf(p, vr[u].y, o.y);
+                    o.z = fmaf(p, vr[u].z, o.z); o.w = fmaf(p, vr[u].w, o.w);
+                }
+                // a wave without any key (S + 1 < 8 never happens after a prefill, but stay safe): m = -inf -> p = NaN; zero it
+                if (!(m > -INFINITY)) { lsum = 0.f; o = make_float4(0.f, 0.f, 0.f, 0.f); }
+                float* m_s = ascr + 3 * 256;
+                float* l_s = m_s + kPCW;
+                if (lane == 0) { m_s[wave] = m; l_s[wave] = lsum; }
+                *reinterpret_cast<float4*>(o_s + wave * 256 + lane * 4) = o;
+                cbar(c);
+                stamp_at(l, 1, 1);
+                // every wave merges the eight states into the normalised head output it multiplies with
+                float mm[kPCW], ll[kPCW];
+                float4 oo[kPCW];
+#pragma unroll
+                for (int g = 0; g < kPCW; ++g) { mm[g] = m_s[g]; ll[g] = l_s[g]; oo[g] = *reinterpret_cast<const float4*>(o_s + g * 256 + lane * 4); }
+                float M = mm[0];
+#pragma unroll
+                for (int g = 1; g < kPCW; ++g) M = fmaxf(M, mm[g]);
+                float Lt = 0.f;
+                float4 oh[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+                for (int g = 0; g < kPCW; ++g) {
+                    const float wgt = __expf(mm[g] - M);
+                    Lt += wgt * ll[g];
+                    oh[0].x = fmaf(wgt, oo[g].x, oh[0].x); oh[0].y = fmaf(wgt, oo[g].y, oh[0].y);
+                    oh[0].z = fmaf(wgt, oo[g].z, oh[0].z); oh[0].w = fmaf(wgt, oo[g].w, oh[0].w);
+                }
+                const float inv = 1.0f / Lt;
+                oh[0].x *= inv; oh[0].y *= inv; oh[0].z *= inv; oh[0].w *= inv;
+                stamp_at(l, 2, 0);
+                if (r0 < RF) {
+                    wait_fill(c, fs + ((unsigned)(r1 < RF ? r1 : r0) * 1024u + 1023u >> 14));
+                    const float p0 = row_partial<1>(ring, rmask, fs, (unsigned)r0 * 1024u, lane, oh);
+                    const float p1 = r1 < RF ? row_partial<1>(ring, rmask, fs, (unsigned)r1 * 1024u, lane, oh) : 0.f;
+                    float s0 = wave_sum(p0), s1 = wave_sum(p1);
+                    if (fh == 0) {                                       // plane 0 carries the residual (x of this layer is still in xvec) and the bias
+                        s0 = xvec[fi * RF + r0] + (s0 + bias0);
+                        if (r1 < RF) s1 = xvec[fi * RF + r1] + (s1 + bias1);
+                    }
+                    if (lane == 0) publish(grs, iX0 + fh * D + fi * RF + r0, tag_of(l, 2), s0);
+                    if (lane == 1 && r1 < RF) publish(grs, iX0 + fh * D + fi * RF + r1, tag_of(l, 2), s1);
+                }
+                fs += nfC;
+                phase_done();
+                stamp_at(l, 2, 1);
+            } else
             // =================== C: merge chunk partials -> attn c_proj (row, K-half) units -> x' = x + ... ===================
             {
                 GVC_PHASE_BEGIN();
@@ -641,7 +767,10 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int nmy = wave < RD ? (RD - wave + kPCW - 1) / kPCW : 0;
                 const int row_g = wg * RD + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.fc_b[row_g] : 0.f;
-                gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
+                if (!fused) gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
+                else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
+                else if (H == 2) gather<NJX, 2>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
+                else gather<NJX, 1>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 cbar(c);
                 stamp_at(l, 3, 0);
                 float val = 0.f;
