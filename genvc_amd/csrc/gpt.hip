@@ -639,6 +639,18 @@ static int persist_prepare(gvc_gpt* c) {
     int rc;
     if ((rc = persist_set_attr<1>(c->p_lds)) || (rc = persist_set_attr<2>(c->p_lds)) || (rc = persist_set_attr<3>(c->p_lds)) ||
         (rc = persist_set_attr<4>(c->p_lds))) return rc;
+    // one workgroup per CU must fit (registers, LDS): otherwise the one-launch step is switched off for this context
+    int per_cu = 0;
+    const int nd = d / 256;
+    hipError_t oe = nd == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<4>, kPThreads, c->p_lds)
+                  : nd == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<3>, kPThreads, c->p_lds)
+                  : nd == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<2>, kPThreads, c->p_lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<1>, kPThreads, c->p_lds);
+    if (oe != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        c->persist = 0;
+        return GVC_OK;
+    }
     PersistLayer* dev = nullptr;
     GVC_CHECK_HIP(hipMalloc((void**)&dev, L * sizeof(PersistLayer)));
     GVC_CHECK_HIP(hipMemcpy(dev, t.data(), L * sizeof(PersistLayer), hipMemcpyHostToDevice));
@@ -778,10 +790,8 @@ extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, 
     if (rc) return rc;
     GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots, GVC_ERR_ARG, "decode_step: B=%d outside [1,%d]", B, c->dm.max_slots);
     hipStream_t s = (hipStream_t)sv;
-    if (persist_ok(c, B)) {
-        if ((rc = persist_prepare(c))) return rc;
-        return launch_persist(c, slots, tok_in, logits_out, latent_out, nullptr, s);
-    }
+    if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
+    if (persist_ok(c, B)) return launch_persist(c, slots, tok_in, logits_out, latent_out, nullptr, s);
     if (rows_decode_ok(c, B)) return decode_rows(c, slots, B, tok_in, logits_out, latent_out, nullptr, s);
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
