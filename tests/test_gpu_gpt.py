@@ -570,3 +570,30 @@ def test_other_model_dims_vs_oracle(d, H, L, persist, monkeypatch):
     rel = eng.latents(torch.zeros(1, device=dev, dtype=torch.int32), prefix[:1].contiguous(), gen.to(dev).int().contiguous())
     np.testing.assert_allclose(rel.cpu().numpy(), O.gpt_latents(wc, dims, cond[:1], codes[:1], gen).numpy(), atol=1e-4)
     _cache.clear()
+
+
+@pytest.mark.parametrize("Tc,n", [(13, 40), (402, 48)], ids=["short_context_fused_attention_phase", "long_context_multi_pass_chunks"])
+def test_one_launch_step_context_regimes_vs_oracle(Tc, n):
+    """the one-launch decode step at head_dim 256 with two heads (d = 512): contexts of 48..88 keys cross the 80-key switch from
+    the fused attention + projection phase to the chunked phases mid-run; a 437-row prefix gives 8 key chunks of 55..61 keys,
+    i.e. two register passes per chunk.  Teacher-forced logits against the oracle at every step."""
+    from oracle import genvc_oracle as O
+    margs = dict(gcfg.TINY_MODEL_ARGS, gpt_layers=2, gpt_n_model_channels=512, gpt_n_heads=2)
+    dims, w, eng = setup(margs, 29)
+    wc = cpu_weights(w)
+    dev = "cuda"
+    cond = synth.uniform(29, "cond", (1, 32, 512), 1.0)
+    codes = synth.integers(29, "codes", (1, Tc), 256)
+    toks = synth.integers(29, "toks", (1, n), 1024)
+    pe, _ = O.compute_embeddings(wc, dims, cond, codes)
+    z, logits, cache = O.gpt_prefill(wc, dims, pe)
+    slots = torch.zeros(1, device=dev, dtype=torch.int32)
+    prefix = eng.prefix_embeddings(cond.to(dev), codes.to(dev).int())
+    lg, lat = eng.prefill(slots, prefix)
+    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4)
+    for j in range(n):
+        z, logits, cache = O.gpt_decode_step(wc, dims, cache, toks[:, j], j + 1)
+        lg, lat = eng.decode_step(slots, toks[:, j].to(dev).int().contiguous())
+        np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4, err_msg=f"step {j} ({pe.shape[1] + 1 + j} cached positions)")
+        np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=1e-4)
+    _cache.clear()
