@@ -144,8 +144,9 @@ __device__ __forceinline__ void publish(__amdgpu_buffer_rsrc_t rs, int index, un
 // Sweep of a phase input by the consumer waves.  The input has NP planes of n granules (a K-split producer publishes
 // one partial sum per plane; the value is their sum, plane 0 first); item t of plane p sits at granule base + p * n + t.
 // A lane reads TWO adjacent granules per load (16 bytes): lane (wave, lane) owns items 2 (wave * 64 + lane) + {0, 1} +
-// j * 128 kPCW, j < NJ.  Load (j = 0, last plane) is the sentinel: it alone is polled until its tags arrive, then the
-// other loads are issued (and everything re-issued if a tag is still old).  n is a multiple of 128.
+// j * 128 kPCW, j < NJ.  Sweeps of more than two loads per lane poll a sentinel first (load j = 0 of the last plane) and issue
+// the other loads when its tags have arrived (everything is re-issued if a tag is still old); one- and two-load sweeps re-read
+// everything in every poll pass, which saves a round trip (measured: 612 vs 630 us per step at 110-250 keys).  n is a multiple of 128.
 template <int NJ, int NP>
 __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code) {
     if (c.dead || c.wave * 128 >= n) return;         // a wave is all in or all out
@@ -154,7 +155,8 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
     constexpr int JT = kPCW * 128;                   // items between loads j and j + 1 of a lane
     unsigned spins = 0;
     pu32x4 v[NJ][NP];
-    while (true) {
+    constexpr bool kSentinel = NJ > 1 || NP > 2;      // one load per lane on <= 2 planes: every poll pass reads everything (one round trip less)
+    while (kSentinel) {
         v[0][NP - 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (NP - 1) * n * 8, 16);
         if (__all(v[0][NP - 1].y == tag && v[0][NP - 1].w == tag)) break;
         if (spin_fail(c, spins, code, 3)) return;
@@ -166,7 +168,7 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
             if (j == 0 || c.wave * 128 + j * JT < n) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    if (!(j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
+                    if (!(kSentinel && j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
             }
         }
 #pragma unroll
