@@ -192,25 +192,6 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
     }
 }
 
-// up to 3 * 64 items whose granule index comes from a map (attention: q_h | k_h | v_h slices), item j * 64 + lane by
-// wave j (one load per lane)
-template <typename Map>
-__device__ __forceinline__ void gather_mapped(PCtx& c, __amdgpu_buffer_rsrc_t rs, int n, unsigned tag, float* dst, int code, Map map) {
-    if (c.dead) return;
-    unsigned spins = 0;
-    for (int tw = c.wave * 64; tw < n; tw += kPCW * 64) {      // (wave-uniform trip count)
-        const int t = tw + c.lane;
-        const int off = map(t < n ? t : 0) * 8;
-        pu32x2 v;
-        while (true) {
-            v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 16);
-            if (__all(t >= n || v.y == tag)) break;
-            if (spin_fail(c, spins, code, 3)) return;
-        }
-        if (t < n) dst[t] = __uint_as_float(v.x);
-    }
-}
-
 template <int VN>
 __device__ __forceinline__ void vec_from_lds(const float* src, int lane, float4 (&v)[VN]) {
 #pragma unroll
@@ -540,8 +521,23 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 load_pass(k0);          // requested ahead of the seam: these rows were written by earlier launches
                 const bool last_chunk = ac == nchunks - 1;
                 const int nseg = last_chunk ? 3 : 1;     // q_h, and the k_h / v_h rows of this very step
-                gather_mapped(c, grs, nseg * hd, tag_of(l, 0), ascr, 200 + l,
-                              [&](int t) { const int sg = t / hd; return iQ + sg * D + ah * hd + (t - sg * hd); });
+                {   // nseg * hd granules as pairs: ONE 16-byte load per lane (a single round trip), item t = 2 (wave * 64 + lane)
+                    const int t = 2 * (wave * 64 + lane);
+                    if (t - 2 * lane < nseg * hd && !c.dead) {           // (wave-uniform)
+                        const bool in = t < nseg * hd;
+                        const int sg = in ? t / hd : 0, tt = in ? t : 0;
+                        const int off = (iQ + sg * D + ah * hd + (tt - sg * hd)) * 8;
+                        const unsigned tg = tag_of(l, 0);
+                        unsigned spins = 0;
+                        pu32x4 v;
+                        while (true) {
+                            v = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
+                            if (__all(!in || (v.y == tg && v.w == tg))) break;
+                            if (spin_fail(c, spins, 200 + l, 3)) break;
+                        }
+                        if (in) *reinterpret_cast<float2*>(ascr + t) = make_float2(__uint_as_float(v.x), __uint_as_float(v.z));
+                    }
+                }
                 cbar(c);
                 stamp_at(l, 1, 0);
                 const float4 q4 = *reinterpret_cast<const float4*>(ascr + dl);
