@@ -113,8 +113,13 @@ __device__ __forceinline__ void cbar(PCtx& c) {
     c.bar_target += kPCW;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (c.lane == 0) __hip_atomic_fetch_add(c.ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // tight poll first (an LDS round trip per iteration, no sleep, no bookkeeping): the waves of a workgroup arrive within a
+    // fraction of a microsecond of each other; the bounded back-off loop only takes over after ~64 fast polls
+    bool met = false;
+    for (int i = 0; i < 64 && !c.dead; ++i)
+        if (lds_ld(c.ctl + kCtlArrive) >= c.bar_target) { met = true; break; }
     unsigned spins = 0;
-    while (!c.dead && lds_ld(c.ctl + kCtlArrive) < c.bar_target)
+    while (!met && !c.dead && lds_ld(c.ctl + kCtlArrive) < c.bar_target)
         if (spin_fail(c, spins, 900, 0)) break;
     asm volatile("" ::: "memory");
 }
