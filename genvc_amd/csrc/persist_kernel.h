@@ -673,9 +673,10 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 float m = -INFINITY;
 #pragma unroll
                 for (int u = 0; u < kPUF; ++u) {
-                    const float dsum = wave_sum(sc[u]);
-                    sc[u] = u * kPCW + wave <= S ? dsum * scale : -INFINITY;
-                    m = fmaxf(m, sc[u]);
+                    if (u * kPCW + wave <= S) {                          // (wave-uniform: slots past the context cost nothing)
+                        sc[u] = wave_sum(sc[u]) * scale;
+                        m = fmaxf(m, sc[u]);
+                    } else sc[u] = -INFINITY;
                 }
                 float lsum = 0.f;
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
