@@ -62,6 +62,7 @@ _SIGNATURES = {
     "gvc_sample": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32, _P, _P]),
     "gvc_gpt_generate": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, C.POINTER(SampleParams), C.c_int32,
                                    C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P]),
+    "gvc_gpt_decode_variant": (C.c_int, [_P]),
     "gvc_gpt_time_kernel": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, c_f32p, c_i32p, _P]),
     "gvc_perceiver_create": (C.c_int, [C.POINTER(PerceiverDims), C.POINTER(_P)]),
     "gvc_perceiver_destroy": (C.c_int, [_P]),

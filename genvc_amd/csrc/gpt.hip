@@ -239,6 +239,7 @@ struct gvc_gpt {
     unsigned long long* p_dbg = nullptr;   // GVC_PERSIST_STAMPS: wall-clock stamps of workgroup 0
     int p_ring_slots = 0, p_ascr = 0, p_hvec = 0;
     size_t p_lds = 0;
+    int last_variant = 0;             // decode variant of the last gvc_gpt_generate call (gvc_gpt_decode_variant)
 };
 
 static int gemv_init();
@@ -1075,6 +1076,7 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     const bool fused = fused_ok(c, B, key_bound);
     const int key = B * 2 + (fused ? 1 : 0);          // (rows mode and the one-launch step are pure functions of B: same key)
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
+    c->last_variant = persist_ok(c, B) ? 3 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;
@@ -1151,6 +1153,8 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
     if (n_launches) *n_launches = n;
     return GVC_OK;
 }
+
+extern "C" int gvc_gpt_decode_variant(gvc_gpt* c) { return c ? c->last_variant : 0; }
 
 // debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {

@@ -126,6 +126,10 @@ class GptEngine:
                                      ptr(_i32(finished)), C.byref(params), i0, n_steps, int(max_keys), ptr(tokens_out),
                                      tokens_out.stride(0), ptr(latents_out), lat_stride, stream()), "generate")
 
+    def decode_variant(self):
+        """which decode step the last generate() call replayed (include/genvc_hip.h: gvc_gpt_decode_variant)"""
+        return int(lib().gvc_gpt_decode_variant(self._h))
+
     def time_kernel(self, which, slots, tok, n_steps):
         """(mean us per launch, launches) of one kernel class of the decode step, launched back to back"""
         avg, n = C.c_float(), C.c_int32()

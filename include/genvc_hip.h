@@ -164,6 +164,11 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
                      int32_t n_steps, int32_t max_keys, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
                      int32_t lat_stride, gvc_stream s);
 
+/* Which decode step the last gvc_gpt_generate call replayed (diagnostic): 0 none yet, 1 launch-per-phase with split-key attention,
+ * 2 launch-per-phase with the fused short-context attention launch, 3 the one-launch step (one fp32 stream), 4 the MFMA rows path
+ * (>= 5 streams). */
+int gvc_gpt_decode_variant(gvc_gpt* ctx);
+
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head
  * GEMV) for every layer, n_steps times back to back on the stream between two hipEvents, and returns the

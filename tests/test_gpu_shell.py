@@ -338,3 +338,34 @@ def test_short_tail_segment_is_zero_padded_like_the_reference():
     assert torch.equal(toks_st[keep], torch.cat(nst["codes"]))
     assert len(st["tokens"]) >= 2 and bool(torch.isfinite(st["wav"]).all())
     _m.clear()
+
+
+@pytest.mark.parametrize("persist,expect", [("1", 3), ("0", 2)], ids=["one_launch_step", "launch_per_phase"])
+def test_harness_generation_takes_the_short_context_decode_variant(persist, expect, monkeypatch):
+    """round-1 advisor finding: `GPT._start` sizes the ids rows for the 602-token cap, and the library used to read the context
+    bound off that width, so `infer.py --streaming` never got the short-context decode step the benchmark measured.  The shell now
+    passes the context length a call reaches (`max_keys`): a 1 s chunk through `get_generator` replays the same variant as the
+    benchmark's engine-level loop -- the one-launch step, or with GVC_PERSIST=0 the fused short-context launches (head_dim 256)."""
+    from genvc_amd.layers.gpt import GPT
+    monkeypatch.setenv("GVC_PERSIST", persist)
+    g = GPT(layers=2, model_dim=512, heads=2).to(DEV)
+    dims = g.dims()
+    sd = {k: v for k, v in synth.make_weights(31, synth.gpt_weight_spec(dims), device=DEV).items()}
+    missing, unexpected = g.load_state_dict(sd, strict=False)
+    assert not unexpected
+    g.init_gpt_for_inference(max_slots=2)
+    cond = synth.uniform(31, "cond", (1, 32, 512), 1.0).to(DEV)
+    codes = synth.integers(31, "codes", (1, 13), 256).to(DEV)
+    fake = g.compute_embeddings(cond, codes)
+    assert fake.shape[1] == 48
+    gen = g.get_generator(fake, stream_group=8, **GREEDY)
+    for _ in range(8):
+        next(gen)
+    assert g.engine.decode_variant() == expect
+    # a 6 s segment's context (110 + 141 positions) is beyond the short-context launches: split-key attention on that path
+    codes6 = synth.integers(31, "codes6", (1, 75), 256).to(DEV)
+    gen = g.get_generator(g.compute_embeddings(cond, codes6), stream_group=8, max_new_tokens=32, **GREEDY)
+    for _ in range(32):
+        next(gen)
+    assert g.engine.decode_variant() == (3 if persist == "1" else 1)
+    g.engine.close()
