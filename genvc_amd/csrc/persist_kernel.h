@@ -13,10 +13,11 @@
 //     they can poll.  A single wave retires an instruction every ~5-10 ns, so the work of a phase is spread over
 //     all eight waves (rows, or K-halves of a row whose two partial sums are added by the NEXT phase's gather);
 //   * a seam (all-to-all hand-off of a phase output) is a sweep over 8-byte {value, tag} granules: every output
-//     element is written by ONE write-through (sc1) store and polled with sc1 loads until its tag is the expected one.
-//     A sweep first polls one sentinel granule per lane (1/4 .. 1/8 of the traffic and of the instructions of a full
-//     sweep) and reads the rest when the sentinels have arrived.  The tag encodes (step epoch, layer, phase); nothing is
-//     zeroed between steps, the epoch lives in device memory and is bumped by the last workgroup to finish the step.
+//     element is written by ONE write-through (sc1) store and polled with sc1 loads (16 bytes = two granules per lane
+//     and load) until its tag is the expected one.  A sweep of one or two loads per lane re-reads everything in every poll
+//     pass (one round trip once the data is there); larger sweeps poll one sentinel load per lane and read the rest when it
+//     has arrived.  The tag encodes (step epoch, layer, phase); nothing is zeroed between steps, the epoch lives in
+//     device memory and is bumped by the last workgroup to finish the step.
 // Per layer: A [LN1, c_attn] -> B [attention, split over <= 8 key chunks per head, a few workgroups] ->
 //            C [merge of the chunk partials, attn c_proj, residual] -> D [LN2, c_fc, gelu_new] -> E [mlp c_proj, residual];
 // then the double-LayerNorm head.  Contexts of <= 80 keys (head_dim 256, <= 4 heads) fuse B and C (persist_fused_attn).
