@@ -241,30 +241,38 @@ __global__ void k_to_fm16_bf16(const float* src, unsigned short* dst, int N, int
 // ---- row completion + LayerNorm, ONE WAVE PER ROW (the order every path shares, fused or not) ----
 // lane L owns the float4s at k = (i*64 + L)*4, i < NV (d = 256*NV).  v = x + bias + part[0] + ... + part[SK-1] (in that
 // order); mean and variance by a per-lane sum over i followed by wave_sum.
-template <int NV>
-__device__ __forceinline__ void row_sum(const float* xr, const float* part, size_t prow, size_t pstride, int SK, const float* bias,
-                                        int lane, float4 (&v)[NV]) {
-    // SK is 4 on every caller's path (wave-uniform branch); the general case loops
-    float4 b4[NV], p4[NV][4];
+template <int NV> struct RowOps { float4 x[NV], b[NV], p[NV][4]; };
+
+// the loads of a row completion, and the sums over them.  PART = false: the row is x alone.  SK4 = true: the four partial
+// planes are requested by row_issue; otherwise row_finish reads the SK planes itself.
+template <int NV, bool PART, bool SK4>
+__device__ __forceinline__ void row_issue(const float* xr, const float* part, size_t prow, size_t pstride, const float* bias, int lane,
+                                          RowOps<NV>& r) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k = (i * 64 + lane) * 4;
-        v[i] = *reinterpret_cast<const float4*>(xr + k);
-        if (part) {
-            b4[i] = *reinterpret_cast<const float4*>(bias + k);
-            if (SK == 4) {
+        r.x[i] = *reinterpret_cast<const float4*>(xr + k);
+        if (PART) {
+            r.b[i] = *reinterpret_cast<const float4*>(bias + k);
+            if (SK4) {
 #pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) p4[i][sidx] = *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k);
+                for (int sidx = 0; sidx < 4; ++sidx) r.p[i][sidx] = *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k);
             }
         }
     }
-    if (part) {
+}
+
+template <int NV, bool PART, bool SK4>
+__device__ __forceinline__ void row_finish(const RowOps<NV>& r, const float* part, size_t prow, size_t pstride, int SK, int lane,
+                                           float4 (&v)[NV]) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[i].x += b4[i].x; v[i].y += b4[i].y; v[i].z += b4[i].z; v[i].w += b4[i].w;
-            if (SK == 4) {
+    for (int i = 0; i < NV; ++i) {
+        v[i] = r.x[i];
+        if (PART) {
+            v[i].x += r.b[i].x; v[i].y += r.b[i].y; v[i].z += r.b[i].z; v[i].w += r.b[i].w;
+            if (SK4) {
 #pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) { v[i].x += p4[i][sidx].x; v[i].y += p4[i][sidx].y; v[i].z += p4[i][sidx].z; v[i].w += p4[i][sidx].w; }
+                for (int sidx = 0; sidx < 4; ++sidx) { v[i].x += r.p[i][sidx].x; v[i].y += r.p[i][sidx].y; v[i].z += r.p[i][sidx].z; v[i].w += r.p[i][sidx].w; }
             } else {
                 const int k = (i * 64 + lane) * 4;
                 for (int sidx = 0; sidx < SK; ++sidx) {
@@ -273,6 +281,23 @@ __device__ __forceinline__ void row_sum(const float* xr, const float* part, size
                 }
             }
         }
+    }
+}
+
+// SK is 4 on every caller's path (wave-uniform branches); the general case loops
+template <int NV>
+__device__ __forceinline__ void row_sum(const float* xr, const float* part, size_t prow, size_t pstride, int SK, const float* bias,
+                                        int lane, float4 (&v)[NV]) {
+    RowOps<NV> r;
+    if (!part) {
+        row_issue<NV, false, false>(xr, part, prow, pstride, bias, lane, r);
+        row_finish<NV, false, false>(r, part, prow, pstride, SK, lane, v);
+    } else if (SK == 4) {
+        row_issue<NV, true, true>(xr, part, prow, pstride, bias, lane, r);
+        row_finish<NV, true, true>(r, part, prow, pstride, SK, lane, v);
+    } else {
+        row_issue<NV, true, false>(xr, part, prow, pstride, bias, lane, r);
+        row_finish<NV, true, false>(r, part, prow, pstride, SK, lane, v);
     }
 }
 
@@ -338,6 +363,52 @@ int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* p
 // workgroups are still reading x_in).  Everything else as k_gemm_skinny<1, 8>: same per-element summation order, so the
 // result is bit-identical to k_ln_sum_rows_t followed by k_gemm_skinny.
 
+// one completed row: kept in x_out by workgroup 0, normalised, staged in LDS in the FM16 fragment order (zeros past the last row)
+template <int NV>
+__device__ __forceinline__ void skinny_ln_row(const LnFuse& P, bool has, int row, const float4 (&v)[NV], bool keep, int lane, float* a_lds) {
+    constexpr int K = 256 * NV;
+    float4 o[NV];
+    if (has) {
+        if (P.x_out && keep) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(P.x_out + (size_t)row * K + (i * 64 + lane) * 4) = v[i];
+        }
+        row_ln<NV>(v, P.ln_w, P.ln_b, lane, o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(a_lds + (size_t)(k >> 4) * 256 + (((row & 15) + 16 * ((k & 15) >> 2)) << 2)) = o[i];
+    }
+}
+
+// request order: row `wave`'s operands (L2), the weight fragments (HBM), then row `wave + 8`'s operands while the first
+// row is normalised: the weight fetch is in flight under the whole prologue.  The compiler barriers pin that order.
+// (rows past the last one read the last row again and stage zeros: straight-line code, nothing lands in scratch)
+template <int NV, bool PART, typename wraw_t, int U>
+__device__ __forceinline__ void skinny_ln_prologue(const LnFuse& P, const wraw_t* wp, wraw_t (&w4)[U], int wave, int lane, bool keep, float* a_lds) {
+    constexpr int K = 256 * NV;
+    const bool has0 = wave < P.rows, has1 = wave + 8 < P.rows;
+    const int r0 = has0 ? wave : P.rows - 1, r1 = has1 ? wave + 8 : r0;
+    const size_t ps = (size_t)P.rows * K;
+    RowOps<NV> ops0, ops1;
+    float4 v0[NV], v1[NV];
+    row_issue<NV, PART, true>(P.x_in + (size_t)r0 * K, P.part, (size_t)r0 * K, ps, P.pbias, lane, ops0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u) w4[u] = wp[u * 64];
+    asm volatile("" ::: "memory");
+    row_finish<NV, PART, true>(ops0, P.part, (size_t)r0 * K, ps, 4, lane, v0);
+    if (P.rows > 8) row_issue<NV, PART, true>(P.x_in + (size_t)r1 * K, P.part, (size_t)r1 * K, ps, P.pbias, lane, ops1);
+    asm volatile("" ::: "memory");
+    skinny_ln_row<NV>(P, has0, wave, v0, keep, lane, a_lds);
+    if (P.rows > 8) row_finish<NV, PART, true>(ops1, P.part, (size_t)r1 * K, ps, 4, lane, v1);
+    skinny_ln_row<NV>(P, has1, wave + 8, v1, keep, lane, a_lds);
+}
+
 template <int NV, int WB = 0>
 __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const LnFuse P) {
     constexpr int K = 256 * NV, K16 = K / 16, NW = 8, kw = K / NW;           // kw = 128 (d = 1024) or 32 (d = 256)
@@ -350,36 +421,8 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
     typedef typename WRaw<WB>::T wraw_t;
     wraw_t w4[U];
     const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)(n0 >> 4) * K16 + (wave * kw >> 4)) * 64 + lane;
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int row = wave + 8 * rr;
-        float4 o[NV];
-        if (row < P.rows) {
-            float4 v[NV];
-            row_sum<NV>(P.x_in + (size_t)row * K, P.part, (size_t)row * K, (size_t)P.rows * K, P.SK, P.pbias, lane, v);
-            if (rr == 1) {          // the weight fragments are requested once the prologue's own operands are on their way
-#pragma unroll
-                for (int u = 0; u < U; ++u) w4[u] = wp[u * 64];
-            }
-            if (P.x_out && blockIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(P.x_out + (size_t)row * K + (i * 64 + lane) * 4) = v[i];
-            }
-            row_ln<NV>(v, P.ln_w, P.ln_b, lane, o);
-        } else {
-            if (rr == 1) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) w4[u] = wp[u * 64];
-            }
-#pragma unroll
-            for (int i = 0; i < NV; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int k = (i * 64 + lane) * 4;
-            *reinterpret_cast<float4*>(a_lds + (size_t)(k >> 4) * 256 + (((row & 15) + 16 * ((k & 15) >> 2)) << 2)) = o[i];
-        }
-    }
+    if (P.part) skinny_ln_prologue<NV, true, wraw_t, U>(P, wp, w4, wave, lane, blockIdx.x == 0, a_lds);
+    else skinny_ln_prologue<NV, false, wraw_t, U>(P, wp, w4, wave, lane, blockIdx.x == 0, a_lds);
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* ap = a_lds + (size_t)(wave * kw >> 4) * 256 + lane * 4;
@@ -406,7 +449,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
 }
 
 int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
-    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && G.K % 256 == 0 && G.K >= 256 && G.K <= 1024, GVC_ERR_ARG,
+    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && G.K % 256 == 0 && G.K >= 256 && G.K <= 1024 && (!P.part || P.SK == 4), GVC_ERR_ARG,
                 "skinny gemm + LN: unsupported shape M=%d N=%d K=%d", G.M, G.N, G.K);
     G.SK = 1;
     const size_t lds = ((size_t)16 * G.K + 8 * 256) * sizeof(float);
