@@ -55,9 +55,9 @@ struct GemmArgs {
     GemmEpi e;
 };
 
-__device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, int n, float v) {
+// everything after the bias (callers whose lanes keep one column add the bias value they loaded once)
+__device__ __forceinline__ void gemm_store_nb(const GemmArgs& G, int batch, int m, int n, float v) {
     const GemmEpi& e = G.e;
-    if (e.bias) v += e.bias[batch * e.bias_batch_stride + n];
     if (e.act == ACT_GELU_NEW) v = gelu_new(v);
     else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (e.act == ACT_GELU_ERF) v = gelu_erf(v);
@@ -85,6 +85,57 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, 
     G.C[batch * G.c_batch_stride + (size_t)m * G.ldc + n] = v;
 }
 
+__device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, int n, float v) {
+    if (G.e.bias) v += G.e.bias[batch * G.e.bias_batch_stride + n];
+    gemm_store_nb(G, batch, m, n, v);
+}
+
+// gemm_store for four consecutive columns n .. n+3 (n % 4 == 0) of row m: the same arithmetic per element, 16-byte accesses.
+// Needs ldc, ldr, d, head_dim % 4 == 0 and 16-byte aligned bases (true of every caller's buffers).
+__device__ __forceinline__ void gemm_store4(const GemmArgs& G, int m, int n, float4 v) {
+    const GemmEpi& e = G.e;
+    if (e.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (e.act == ACT_GELU_NEW) { v.x = gelu_new(v.x); v.y = gelu_new(v.y); v.z = gelu_new(v.z); v.w = gelu_new(v.w); }
+    else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (e.act == ACT_GELU_ERF) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    if (e.qkv) {
+        const int which = n / e.d;
+        const int c = n - which * e.d;
+        if (which == 0) {
+            *reinterpret_cast<float4*>(G.C + (size_t)m * G.ldc + c) = v;
+        } else {
+            const int b = m / e.T, t = m - b * e.T;
+            const int slot = e.slots[b];
+            const int pos = t + (e.base_len ? e.base_len[slot] : 0);
+            const int h = c / e.head_dim, j = c - h * e.head_dim;
+            float* cache = which == 1 ? e.kcache : e.vcache;
+            const size_t at = (((size_t)slot * e.n_head + h) * e.max_seq + pos) * e.head_dim + j;
+            if (e.kv_bf16) {
+                ushort4 o;
+                o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(cache) + at) = o;
+            } else {
+                *reinterpret_cast<float4*>(cache + at) = v;
+            }
+        }
+        return;
+    }
+    if (e.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(e.resid + (size_t)m * e.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (e.resid2) {
+        const float4 r = *reinterpret_cast<const float4*>(e.resid2 + (size_t)m * e.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (e.out_scale != 0.f) { v.x *= e.out_scale; v.y *= e.out_scale; v.z *= e.out_scale; v.w *= e.out_scale; }
+    if (e.c_fm16) { *reinterpret_cast<float4*>(G.C + fm16_index(m, n, G.N)) = v; return; }
+    *reinterpret_cast<float4*>(G.C + (size_t)m * G.ldc + n) = v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G);
@@ -108,6 +159,12 @@ struct LnFuse {
     int rows;
 };
 int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s);
+// Strip GEMM for more rows than the skinny kernels take (batched prefill, latent re-pass): FM16 operands, N % 64 == 0.  One
+// workgroup per (m group <= 9 tiles, 64 columns, K split): A staged once per workgroup in LDS by LDS-DMA, weights streamed per
+// wave, MFMA-bound inner loop (gemm.hip).  sk_max > 1 allows a K split when the grid would not fill the GPU: raw partials
+// go to G.work[sk][M][N]; raw_partials = 1 leaves them for the consumer (k_ln_sum_rows) and reports the split in *sk_used,
+// raw_partials = 0 runs k_splitk_epilogue (G.e applied there).
+int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partials, int* sk_used, hipStream_t s);
 void gemm_init_attributes();        // raises dynamic-LDS limits; call once, outside stream capture
 // row-major [N][K] -> FM16
 __global__ void k_to_fm16(const float* src, float* dst, int N, int K);

@@ -1,5 +1,6 @@
 // fp32 MFMA GEMM (see gemm.h)
 #include "gemm.h"
+#include <algorithm>
 
 namespace gvc {
 
@@ -464,10 +465,6 @@ int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
     return GVC_OK;
 }
 
-void gemm_init_attributes() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-}
 
 int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
     const int MT = cdiv(G.M, 16);
@@ -492,4 +489,270 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
     return GVC_OK;
 }
 
+// ---- strip GEMM for 17 .. a few thousand rows (batched prefill, latent re-pass): see gemm.h ----
+// A workgroup = 4 waves = one (m group, 64-column n block, K split).  The m group's A tiles are staged ONCE per workgroup in
+// LDS by LDS-DMA (a 16x16 FM16 block is 1 KiB contiguous = one global_load_lds of 16 bytes per lane), in stages of KC k-blocks,
+// two stage buffers; every wave streams the weights of its own 16 columns straight from global memory into MFMA operands
+// (one float4 per lane per k-block, requested a stage ahead) and keeps MTW independent 16x16 accumulators, so an A fragment
+// read from LDS feeds 4 MFMAs and a weight fragment 4*MTW.  Per k-block and wave: 1 global float4, MTW ds_read_b128,
+// 4*MTW v_mfma_f32_16x16x4_f32 (32 cycles each): the loop is bound by the MFMA pipe.
+struct StripGeom { int MG, NB, SK, mt, kb, dbg; };    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
+
+template <int MTW> struct StripCfg {
+    static constexpr int KC = 36 / MTW > 12 ? 12 : 36 / MTW;         // k-blocks per stage: <= 36 KiB of A per stage, two workgroups fit a CU
+    static constexpr size_t stage_bytes = (size_t)2 * KC * MTW * 1024, tile_bytes = (size_t)MTW * 16 * 68 * 4;
+    static constexpr size_t lds_bytes = stage_bytes > tile_bytes ? stage_bytes : tile_bytes;
+};
+
+// ds_read_b128 of the MTW fragments of one k-block of a stage (tile t at byte t * 1024 from `addr`), and the wait that
+// orders their consumers behind the data (the registers pass through the asm so that nothing is scheduled across it)
+template <int MTW, int T = 0>
+__device__ __forceinline__ void strip_read(f32x4 (&a)[MTW], unsigned addr) {
+    if constexpr (T < MTW) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[T]) : "v"(addr), "n"(T * 1024));
+        strip_read<MTW, T + 1>(a, addr);
+    }
+}
+template <int MTW>
+__device__ __forceinline__ void strip_wait(f32x4 (&a)[MTW]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) asm volatile("" : "+v"(a[t]));
+}
+
+template <int MTW, int WB>
+__global__ __launch_bounds__(256) void k_gemm_strip(const GemmArgs G, const StripGeom S) {
+    constexpr int KC = StripCfg<MTW>::KC;
+    extern __shared__ __attribute__((aligned(16))) float strip_lds[];        // [2][KC][MTW][256]
+    typedef typename WRaw<WB>::T wraw_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id = blockIdx.x;
+    const int nb = id % S.NB;       // n block fastest: the m groups / K splits of one n block share an XCD (NB % 8 == 0) and its L2
+    id /= S.NB;
+    const int mg = id % S.MG, sk = id / S.MG;
+    const int t_lo = (int)((long long)mg * S.mt / S.MG), nt = (int)((long long)(mg + 1) * S.mt / S.MG) - t_lo;     // <= MTW
+    const int kb_lo = (int)((long long)sk * S.kb / S.SK), nkb = (int)((long long)(sk + 1) * S.kb / S.SK) - kb_lo;
+    const int n_tile = nb * 4 + wave;
+    const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)n_tile * S.kb + kb_lo) * 64 + lane;
+    const float* abase = G.A + ((size_t)t_lo * S.kb + kb_lo) * 256 + lane * 4;
+    const int nst = (nkb + KC - 1) / KC;
+    const unsigned lds_base = (unsigned)(size_t)strip_lds + (unsigned)lane * 16u;       // LDS byte address of this lane's float4 in block 0
+
+    // this wave's share of a stage's A blocks: pairs p = wave + 4 i -> (t = p / KC, kc = p % KC)
+    auto stage_a = [&](int st, int buf) {
+        constexpr int NP = (MTW * KC + 3) / 4;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pidx = wave + 4 * i;
+            const int t = pidx / KC, kc = pidx - t * KC;
+            const int kbi = st * KC + kc;
+            if (pidx < MTW * KC && t < nt && kbi < nkb)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + ((size_t)t * S.kb + kbi) * 256),
+                                                 (__attribute__((address_space(3))) void*)(strip_lds + ((size_t)(buf * KC + kc) * MTW + t) * 256),
+                                                 16, 0, 0);
+        }
+    };
+    wraw_t wnext[KC], wcur[KC];
+    auto stage_w = [&](int st) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const int kbi = min(st * KC + kc, nkb - 1);          // (past the end: a valid block again, never used)
+            wnext[kc] = wp[(size_t)kbi * 64];
+        }
+    };
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+
+    stage_a(0, 0);
+    stage_w(0);
+    for (int st = 0; st < ((S.dbg & 8) ? 1 : nst); ++st) {
+        const int buf = st & 1;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) wcur[kc] = wnext[kc];
+        // everything this wave requested has landed (stage st of A, in LDS, included); past the barrier that holds for all four
+        // waves, and every wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // the A fragments are read with ds_read_b128 issued from inline asm: a ds_read the compiler can see makes it drain vmcnt
+        // first (the LDS-DMA of the NEXT stage might alias), which serialises the stage's memory latency with its MFMAs.
+        // Fragments of k-block kc + 1 are requested right before the MFMAs of k-block kc are issued.
+        const unsigned ab = lds_base + (unsigned)(buf * KC * MTW * 1024);
+        const int kcs = min(KC, nkb - st * KC);
+        f32x4 af[2][MTW];
+        strip_read<MTW>(af[0], ab);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            if (kc < kcs && !(S.dbg & 2)) {
+                strip_wait<MTW>(af[kc & 1]);
+                if (kc + 1 < KC && kc + 1 < kcs) strip_read<MTW>(af[(kc + 1) & 1], ab + (unsigned)((kc + 1) * MTW * 1024));
+                const float4 wv = w_f4(wcur[kc]);
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][0], wv.x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][1], wv.y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][2], wv.z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][3], wv.w, acc[t], 0, 0, 0);
+            }
+            // the next stage's requests go out behind the first k-block's MFMAs: their issue time is off the critical path
+            if (kc == 0 && st + 1 < nst && !(S.dbg & 1)) {
+                stage_a(st + 1, buf ^ 1);
+                stage_w(st + 1);
+            }
+        }
+    }
+    // Epilogue through LDS: a lane holds rows 4*(lane>>4) + q, column lane & 15 of each 16x16 tile -- 4-byte stores in 64-byte
+    // row pieces, which the write path takes at under 1 TB/s.  The accumulators are laid out as the workgroup's
+    // [16*MTW rows][64 columns] tile in LDS and go out as float4: rows of 256 contiguous bytes (four rows per wave store), or,
+    // for a fragment-major destination, each wave's own 16x16 tile as one contiguous 1 KiB block.
+    constexpr int LDT = 68;
+    __syncthreads();                    // every wave is done with the stage buffers
+    if (!(S.dbg & 4)) {
+        float* T = strip_lds;
+#pragma unroll
+        for (int t = 0; t < MTW; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[(t * 16 + 4 * (lane >> 4) + q) * LDT + wave * 16 + (lane & 15)] = acc[t][q];
+        const bool fm = S.SK == 1 && G.e.c_fm16;
+        if (!fm) __syncthreads();       // (a fragment-major store reads back only the wave's own columns)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row = fm ? (lane & 15) : wave * 4 + (lane >> 4);
+        const int col = fm ? wave * 16 + 4 * (lane >> 4) : 4 * (lane & 15);
+        const int n = nb * 64 + col;
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+            const int m = (t_lo + t) * 16 + row;
+            if (t < nt && m < G.M) {
+                const float4 v = *reinterpret_cast<const float4*>(T + (t * 16 + row) * LDT + col);
+                if (S.SK > 1) *reinterpret_cast<float4*>(G.work + ((size_t)sk * G.M + m) * G.N + n) = v;
+                else gemm_store4(G, m, n, v);
+            }
+        }
+    }
+}
+
+// geometry: the (tiles per group, K split) pair with the shortest modelled critical path, in units of one (m tile, k block) =
+// 4 MFMAs = 128 cycles: a CU runs its workgroups' MFMA work back to back, and every round of resident workgroups pays one
+// pipeline fill.  GVC_STRIP="MTW,SK" overrides (measurement).
+int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partials, int* sk_used, hipStream_t s) {
+    GVC_REQUIRE(G.M >= 1 && G.N % 64 == 0 && G.K % 16 == 0 && G.conv_cin == 0 && G.a_act == 0 && G.ldc % 4 == 0 &&
+                    (!G.e.resid || G.e.ldr % 4 == 0) && (!G.e.qkv || (G.e.d % 64 == 0 && G.e.head_dim % 4 == 0)), GVC_ERR_ARG,
+                "strip gemm: unsupported shape M=%d N=%d K=%d (FM16 operands, N %% 64 == 0, 16-byte rows)", G.M, G.N, G.K);
+    StripGeom S;
+    S.mt = cdiv(G.M, 16); S.NB = G.N / 64; S.kb = G.K / 16;
+    if (!G.work) sk_max = 1;
+    if (sk_max < 1) sk_max = 1;
+    if (sk_max > 8) sk_max = 8;
+    int best_w = 0, best_sk = 1;
+    double best = 1e30;
+    static const double fill = getenv("GVC_STRIP_FILL") ? atof(getenv("GVC_STRIP_FILL")) : 40.0;
+    for (int w = 1; w <= 9; ++w) {
+        const int MG = cdiv(S.mt, w);
+        if (cdiv(S.mt, MG) != w) continue;              // the balanced partition's largest group: only exact fits are candidates
+        const int wpc = 2;                               // 72 KiB of LDS at most: two workgroups per CU
+        for (int sk = 1; sk <= sk_max; ++sk) {
+            if (S.kb / sk < 4) break;
+            if (sk > 1 && (long long)sk * G.M * G.N > work_cap) break;
+            const long long wgs = (long long)MG * S.NB * sk;
+            const double serial = (double)cdiv((int)wgs, 256) * w * cdiv(S.kb, sk);
+            const double cost = serial + fill * cdiv((int)wgs, 256 * wpc) + (sk > 1 && !raw_partials ? 30.0 : 0.0);
+            if (cost < best) { best = cost; best_w = w; best_sk = sk; }
+        }
+    }
+    static const char* ov = getenv("GVC_STRIP");
+    if (ov) {
+        int w = 0, sk = 0;
+        if (sscanf(ov, "%d,%d", &w, &sk) == 2 && w >= 1 && w <= 9 && sk >= 1 && sk <= sk_max && (sk == 1 || (long long)sk * G.M * G.N <= work_cap)) {
+            best_w = cdiv(S.mt, cdiv(S.mt, w)); best_sk = sk;
+        }
+    }
+    GVC_REQUIRE(best_w > 0, GVC_ERR_ARG, "strip gemm: no geometry for M=%d N=%d K=%d", G.M, G.N, G.K);
+    S.MG = cdiv(S.mt, best_w); S.SK = best_sk;
+    static const int dbg = getenv("GVC_STRIP_DBG") ? atoi(getenv("GVC_STRIP_DBG")) : 0;
+    S.dbg = dbg;
+    G.SK = best_sk;
+    if (sk_used) *sk_used = best_sk;
+    const dim3 grid(S.MG * S.NB * S.SK);
+    static const size_t lds_floor = getenv("GVC_STRIP_LDS") ? (size_t)atoi(getenv("GVC_STRIP_LDS")) * 1024 : 0;
+#define GVC_STRIP(w)                                                                                                         \
+    case w:                                                                                                                  \
+        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_strip<w, 1>), grid, dim3(256), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);              \
+        else hipLaunchKernelGGL((k_gemm_strip<w, 0>), grid, dim3(256), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);                       \
+        break;
+    switch (best_w) { GVC_STRIP(1) GVC_STRIP(2) GVC_STRIP(3) GVC_STRIP(4) GVC_STRIP(5) GVC_STRIP(6) GVC_STRIP(7) GVC_STRIP(8) GVC_STRIP(9) }
+#undef GVC_STRIP
+    GVC_LAUNCH_CHECK();
+    if (best_sk > 1 && !raw_partials) {
+        const long long mn = (long long)G.M * G.N;
+        int gx = (int)((mn + 255) / 256);
+        if (gx > 2048) gx = 2048;
+        hipLaunchKernelGGL(k_splitk_epilogue, dim3(gx, 1, 1), dim3(256), 0, s, G);
+        GVC_LAUNCH_CHECK();
+    }
+    return GVC_OK;
+}
+
+void gemm_init_attributes() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#define GVC_STRIP_ATTR(w)                                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    GVC_STRIP_ATTR(1) GVC_STRIP_ATTR(2) GVC_STRIP_ATTR(3) GVC_STRIP_ATTR(4) GVC_STRIP_ATTR(5) GVC_STRIP_ATTR(6) GVC_STRIP_ATTR(7) GVC_STRIP_ATTR(8) GVC_STRIP_ATTR(9)
+#undef GVC_STRIP_ATTR
+}
+
 }  // namespace gvc
+
+// Measurement / test hook (include/genvc_hip.h): one GEMM C = A W^T (+ bias) through a chosen kernel on row-major operands.
+extern "C" int gvc_gemm_probe(int32_t variant, const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N,
+                              int32_t K, int32_t sk_max, int32_t iters, float* avg_us, gvc_stream sv) {
+    using namespace gvc;
+    GVC_REQUIRE(A && W && C && M >= 1 && N >= 16 && K >= 16 && K % 16 == 0 && N % 16 == 0 && variant >= 0 && variant <= 2, GVC_ERR_ARG,
+                "gemm_probe: bad argument");
+    hipStream_t s = (hipStream_t)sv;
+    static bool attrs = false;
+    if (!attrs) { gemm_init_attributes(); attrs = true; }
+    const int Mp = (M + 15) & ~15;
+    float *Af = nullptr, *Wf = nullptr, *work = nullptr;
+    const long long work_cap = (long long)8 * M * N;
+    GVC_CHECK_HIP(hipMalloc((void**)&work, (size_t)work_cap * sizeof(float)));
+    GemmArgs G;
+    memset(&G, 0, sizeof(G));
+    G.C = C; G.ldc = N; G.M = M; G.N = N; G.K = K; G.work = work; G.e.bias = bias;
+    if (variant == 0) {
+        G.A = A; G.lda = K; G.Wt = W; G.ldw = K;
+    } else {
+        GVC_CHECK_HIP(hipMalloc((void**)&Af, (size_t)Mp * K * sizeof(float)));
+        GVC_CHECK_HIP(hipMalloc((void**)&Wf, (size_t)N * K * sizeof(float)));
+        GVC_CHECK_HIP(hipMemsetAsync(Af, 0, (size_t)Mp * K * sizeof(float), s));
+        hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, A, Af, M, K);
+        hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, W, Wf, N, K);
+        G.A = Af; G.lda = K; G.Wt = Wf; G.ldw = K;
+    }
+    auto once = [&]() -> int {
+        if (variant == 0) return launch_gemm_cap(G, 1, work_cap, s);
+        if (variant == 1) return launch_gemm_strip(G, sk_max, work_cap, 0, nullptr, s);
+        return launch_gemm_skinny(G, 1, work_cap, s);
+    };
+    int rc = once();
+    if (rc == GVC_OK && iters > 0 && avg_us) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, s);
+        for (int i = 0; i < iters && rc == GVC_OK; ++i) rc = once();
+        hipEventRecord(e1, s);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        *avg_us = ms * 1000.f / (float)iters;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    hipStreamSynchronize(s);
+    hipFree(work);
+    if (Af) hipFree(Af);
+    if (Wf) hipFree(Wf);
+    return rc;
+}

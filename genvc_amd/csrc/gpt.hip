@@ -215,6 +215,7 @@ struct gvc_gpt {
     int* seam_err_host = nullptr;                 // pinned, device-visible: a timed-out hand-off of the one-launch step / a full KV cache
     int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
+    int strip_prefill = 1;                        // GVC_STRIP_PREFILL=0: more than 128 rows go to the tiled GEMM
     int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
     float* xalt = nullptr;                        // second residual buffer of that path [16][d]
     int rows_decode_min = 5;                      // batches of at least this many streams decode on the MFMA rows path (0: never);
@@ -290,6 +291,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     c->n_expected = 10 + 12 * (int)L;
     if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
     if (getenv("GVC_FUSE_LN")) c->fuse_ln = atoi(getenv("GVC_FUSE_LN"));
+    if (getenv("GVC_STRIP_PREFILL")) c->strip_prefill = atoi(getenv("GVC_STRIP_PREFILL"));
     gemm_init_attributes();
     GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
     if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
@@ -316,7 +318,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     }
 
     c->kv_layer_stride = (size_t)D.max_slots * D.n_head * D.max_seq * hd;
-    const size_t rows = D.max_rows;
+    const size_t rows = ((size_t)D.max_rows + 15) & ~(size_t)15;       // fragment-major activations come in 16-row tiles
     c->work_cap = 8ll << 20;
     if ((rc = alloc_f(&c->kv, (c->kv_bf16 ? 1 : 2) * L * c->kv_layer_stride)) || (rc = alloc_f(&c->x, rows * d)) ||
         (rc = alloc_f(&c->a, rows * d)) || (rc = alloc_f(&c->q, rows * d)) || (rc = alloc_f(&c->h, rows * 4 * d)) ||
@@ -836,15 +838,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
     const int SKP = 4;
     float* part_proj = c->work;                                    // [SKP][rows][d]
     float* part_p2 = c->work + c->work_cap / 2;                    // [SKP][rows][d]
-    auto ln = [&](const float* w, const float* b) {
-        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, w, b, (const float*)nullptr,
-                           (const float*)nullptr, skinny ? 1 : 0);
-    };
     int ln_rc = GVC_OK;          // (a lambda cannot return through GVC_REQUIRE: the first failure is kept and returned below)
-    auto ln_sum = [&](const float* part, const float* bias, const float* w, const float* b) {
-        const int r = launch_ln_sum_rows(c->x, c->x, c->a, part, SKP, bias, rows, d, w, b, 1, s);
-        if (ln_rc == GVC_OK) ln_rc = r;
-    };
     // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
     // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
@@ -893,56 +887,75 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         // fold the last layer's mlp partials into the residual stream, landing in c->x (what the head reads)
         return launch_ln_sum_rows(X[cur], c->x, c->a, part_p2, SKP, c->layers[c->dm.n_layer - 1].p2_b, rows, d, nullptr, nullptr, 1, s);
     }
+    // more rows than the skinny kernels take: the strip GEMM (gemm.hip) on the same fragment-major operands; the N = d projections
+    // leave raw K-split partials for the next LayerNorm launch exactly as the skinny path does (the split is the launcher's choice)
+    const bool strip = !skinny && c->strip_prefill && c->skinny_prefill && c->wfm && d % 256 == 0 && d <= 1024 &&
+                       (long long)rows * d <= c->work_cap / 2;
+    const bool fm = skinny || strip;
+    auto gemm_fm = [&](GemmArgs& G, int sk_max, int raw, int* sk_used) -> int {
+        if (strip) return launch_gemm_strip(G, sk_max, sk_max > 1 ? c->work_cap / 2 : c->work_cap, raw, sk_used, s);
+        if (sk_used) *sk_used = sk_max;
+        return launch_gemm_skinny(G, sk_max, sk_max > 1 ? c->work_cap / 2 : c->work_cap, s);
+    };
+    auto ln_fm = [&](const float* w, const float* b) {
+        hipLaunchKernelGGL(k_ln_rows, dim3(cdiv(rows, 4)), dim3(256), 0, s, c->x, c->a, rows, d, w, b, (const float*)nullptr,
+                           (const float*)nullptr, fm ? 1 : 0);
+    };
+    auto ln_sum_sk = [&](const float* part, int SK, const float* bias, const float* w, const float* b) {
+        const int r = launch_ln_sum_rows(c->x, c->x, c->a, part, SK, bias, rows, d, w, b, 1, s);
+        if (ln_rc == GVC_OK) ln_rc = r;
+    };
+    int sk_p2 = SKP, sk_proj = SKP;
     for (int l = 0; l < c->dm.n_layer; ++l) {
         const GptLayer& ly = c->layers[l];
-        if (skinny && l > 0) ln_sum(part_p2, c->layers[l - 1].p2_b, ly.ln1_w, ly.ln1_b);
-        else ln(ly.ln1_w, ly.ln1_b);
+        if (fm && l > 0) ln_sum_sk(part_p2, sk_p2, c->layers[l - 1].p2_b, ly.ln1_w, ly.ln1_b);
+        else ln_fm(ly.ln1_w, ly.ln1_b);
         GVC_LAUNCH_CHECK();
         GemmArgs G;
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.qkv_f : ly.qkv_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
+        G.A = c->a; G.lda = d; G.Wt = fm ? ly.qkv_f : ly.qkv_w; G.w_bf16 = fm && c->bf16; G.ldw = d; G.C = c->q; G.ldc = d; G.M = rows; G.N = 3 * d; G.K = d;
         G.work = c->work; G.e.bias = ly.qkv_b; G.e.qkv = 1; G.e.d = d; G.e.n_head = c->dm.n_head;
         G.e.head_dim = c->hd; G.e.max_seq = c->dm.max_seq; G.e.T = T; G.e.slots = slots; G.e.base_len = base_len;
         G.e.kcache = kv_layer(c, l, 0);
         G.e.vcache = kv_layer(c, l, 1);
         G.e.kv_bf16 = c->kv_bf16;
-        if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        if ((rc = fm ? gemm_fm(G, 1, 0, nullptr) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         AttnArgs At = gpt_attn_args(c, l, slots);
         At.q = c->q; At.T = T; At.base_len = base_len;
-        At.out = c->a; At.out_stride = d; At.out_fm16 = skinny ? 1 : 0;
+        At.out = c->a; At.out_stride = d; At.out_fm16 = fm ? 1 : 0;
         // one new row per cached stream (batched decode): 16 waves share the keys of a (row, head)
         if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.proj_f : ly.proj_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
-        if (skinny) {
+        G.A = c->a; G.lda = d; G.Wt = fm ? ly.proj_f : ly.proj_w; G.w_bf16 = fm && c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
+        if (fm) {
             G.work = part_proj;
-            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
-            ln_sum(part_proj, ly.proj_b, ly.ln2_w, ly.ln2_b);
+            if ((rc = gemm_fm(G, strip ? 8 : SKP, 1, &sk_proj))) return rc;
+            ln_sum_sk(part_proj, sk_proj, ly.proj_b, ly.ln2_w, ly.ln2_b);
         } else {
             G.work = c->work; G.e.bias = ly.proj_b; G.e.resid = c->x; G.e.ldr = d;
             if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
-            ln(ly.ln2_w, ly.ln2_b);
+            ln_fm(ly.ln2_w, ly.ln2_b);
         }
         GVC_LAUNCH_CHECK();
         memset(&G, 0, sizeof(G));
-        G.A = c->a; G.lda = d; G.Wt = skinny ? ly.fc_f : ly.fc_w; G.w_bf16 = skinny && c->bf16; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
-        G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = skinny ? 1 : 0;
-        if ((rc = skinny ? launch_gemm_skinny(G, 1, c->work_cap, s) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+        G.A = c->a; G.lda = d; G.Wt = fm ? ly.fc_f : ly.fc_w; G.w_bf16 = fm && c->bf16; G.ldw = d; G.C = c->h; G.ldc = 4 * d; G.M = rows; G.N = 4 * d; G.K = d;
+        G.work = c->work; G.e.bias = ly.fc_b; G.e.act = ACT_GELU_NEW; G.e.c_fm16 = fm ? 1 : 0;
+        if ((rc = fm ? gemm_fm(G, 1, 0, nullptr) : launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
 
         memset(&G, 0, sizeof(G));
-        G.A = c->h; G.lda = 4 * d; G.Wt = skinny ? ly.p2_f : ly.p2_w; G.w_bf16 = skinny && c->bf16; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
-        if (skinny) {
+        G.A = c->h; G.lda = 4 * d; G.Wt = fm ? ly.p2_f : ly.p2_w; G.w_bf16 = fm && c->bf16; G.ldw = 4 * d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = 4 * d;
+        if (fm) {
             G.work = part_p2;
-            if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
+            if ((rc = gemm_fm(G, strip ? 8 : SKP, 1, &sk_p2))) return rc;
         } else {
             G.work = c->work; G.e.bias = ly.p2_b; G.e.resid = c->x; G.e.ldr = d;
             if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
         }
     }
-    if (skinny) {       // fold the last layer's mlp partials into the residual stream
-        ln_sum(part_p2, c->layers[c->dm.n_layer - 1].p2_b, nullptr, nullptr);
+    if (fm) {       // fold the last layer's mlp partials into the residual stream
+        ln_sum_sk(part_p2, sk_p2, c->layers[c->dm.n_layer - 1].p2_b, nullptr, nullptr);
         GVC_LAUNCH_CHECK();
     }
     return ln_rc;

@@ -181,6 +181,14 @@ int gvc_gpt_decode_variant(gvc_gpt* ctx);
 int gvc_gpt_time_kernel(gvc_gpt* ctx, int32_t which, const int32_t* slots, int32_t B, const int32_t* tok_in,
                         int32_t n_steps, float* avg_us, int32_t* n_launches, gvc_stream s);
 
+/* Measurement / test hook for the fp32 MFMA GEMMs under the prefill (not a reference interface): C[M][N] = A[M][K] W[N][K]^T
+ * (+ bias[N], nullable), all row-major device buffers, through one kernel: variant 0 the 64x64x32 tiled kernel, 1 the strip
+ * kernel (operands converted to the fragment-major layout first; K split up to sk_max), 2 the skinny kernel (M <= 128).  With
+ * iters > 0 the GEMM is then launched iters more times between two hipEvents and *avg_us is the mean microseconds per GEMM
+ * (split-K epilogue included).  Synchronises the stream. */
+int gvc_gemm_probe(int32_t variant, const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N, int32_t K,
+                   int32_t sk_max, int32_t iters, float* avg_us, gvc_stream s);
+
 /* ------------------------------------------------------------------------------------------
  * Perceiver resampler.  Replaces layers/perceiver_encoder.py:PerceiverResampler.forward (:265-276)
  * as called by GPT.get_style_emb (gpt.py:351-373) with mask=None.
