@@ -499,7 +499,7 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
 struct StripGeom { int MG, NB, SK, mt, kb, dbg; };    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
 
 template <int MTW> struct StripCfg {
-    static constexpr int KC = 36 / MTW > 12 ? 12 : 36 / MTW;         // k-blocks per stage: <= 36 KiB of A per stage, two workgroups fit a CU
+    static constexpr int KC = MTW >= 5 ? 4 : 8;                      // k-blocks per stage: <= 36 KiB of A per stage         // k-blocks per stage: <= 36 KiB of A per stage, two workgroups fit a CU
     static constexpr size_t stage_bytes = (size_t)2 * KC * MTW * 1024, tile_bytes = (size_t)MTW * 16 * 68 * 4;
     static constexpr size_t lds_bytes = stage_bytes > tile_bytes ? stage_bytes : tile_bytes;
 };
@@ -520,45 +520,47 @@ __device__ __forceinline__ void strip_wait(f32x4 (&a)[MTW]) {
     for (int t = 0; t < MTW; ++t) asm volatile("" : "+v"(a[t]));
 }
 
-template <int MTW, int WB>
-__global__ __launch_bounds__(256) void k_gemm_strip(const GemmArgs G, const StripGeom S) {
-    constexpr int KC = StripCfg<MTW>::KC;
+// KH = 2: eight waves; waves 4..7 take the upper half of every stage's k-blocks for the same four column tiles, so each SIMD
+// has two waves to issue MFMAs from (one wave alone reaches 89 % of the MFMA rate and stalls on its own LDS waits); the two
+// halves' accumulators are added in the epilogue tile (lower half + upper half, a fixed order).
+template <int MTW, int WB, int KH>
+__global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const StripGeom S) {
+    constexpr int KC = StripCfg<MTW>::KC, KCW = KC / KH, NWV = 4 * KH;
     extern __shared__ __attribute__((aligned(16))) float strip_lds[];        // [2][KC][MTW][256]
     typedef typename WRaw<WB>::T wraw_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, kh = wave >> 2;
     int id = blockIdx.x;
     const int nb = id % S.NB;       // n block fastest: the m groups / K splits of one n block share an XCD (NB % 8 == 0) and its L2
     id /= S.NB;
     const int mg = id % S.MG, sk = id / S.MG;
     const int t_lo = (int)((long long)mg * S.mt / S.MG), nt = (int)((long long)(mg + 1) * S.mt / S.MG) - t_lo;     // <= MTW
     const int kb_lo = (int)((long long)sk * S.kb / S.SK), nkb = (int)((long long)(sk + 1) * S.kb / S.SK) - kb_lo;
-    const int n_tile = nb * 4 + wave;
+    const int n_tile = nb * 4 + wn;
     const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)n_tile * S.kb + kb_lo) * 64 + lane;
     const float* abase = G.A + ((size_t)t_lo * S.kb + kb_lo) * 256 + lane * 4;
     const int nst = (nkb + KC - 1) / KC;
     const unsigned lds_base = (unsigned)(size_t)strip_lds + (unsigned)lane * 16u;       // LDS byte address of this lane's float4 in block 0
 
-    // this wave's share of a stage's A blocks: pairs p = wave + 4 i -> (t = p / KC, kc = p % KC)
+    // this wave's share of a stage's A blocks: pairs p = wave + NWV i -> (t = p / KC, kc = p % KC)
     auto stage_a = [&](int st, int buf) {
-        constexpr int NP = (MTW * KC + 3) / 4;
+        constexpr int NP = (MTW * KC + NWV - 1) / NWV;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int pidx = wave + 4 * i;
+            const int pidx = wave + NWV * i;
             const int t = pidx / KC, kc = pidx - t * KC;
-            const int kbi = st * KC + kc;
-            if (pidx < MTW * KC && t < nt && kbi < nkb)
+            const int kbi = min(st * KC + kc, nkb - 1);            // (past the end: a valid block again, met by zero weights)
+            if (pidx < MTW * KC && t < nt)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + ((size_t)t * S.kb + kbi) * 256),
                                                  (__attribute__((address_space(3))) void*)(strip_lds + ((size_t)(buf * KC + kc) * MTW + t) * 256),
                                                  16, 0, 0);
         }
     };
-    wraw_t wnext[KC], wcur[KC];
+    wraw_t wnext[KCW], wcur[KCW];
     auto stage_w = [&](int st) {
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const int kbi = min(st * KC + kc, nkb - 1);          // (past the end: a valid block again, never used)
-            wnext[kc] = wp[(size_t)kbi * 64];
-        }
+        for (int j = 0; j < KCW; ++j)
+            wnext[j] = wp[(size_t)min(st * KC + kh * KCW + j, nkb - 1) * 64];        // (past the end: a valid block again, zeroed at use)
     };
     f32x4 acc[MTW];
 #pragma unroll
@@ -568,36 +570,35 @@ __global__ __launch_bounds__(256) void k_gemm_strip(const GemmArgs G, const Stri
     stage_w(0);
     for (int st = 0; st < ((S.dbg & 8) ? 1 : nst); ++st) {
         const int buf = st & 1;
+        // k-blocks past the end get zero weights, so that the k loop has no tail case (a branch around MFMAs makes the
+        // accumulators commute between AGPRs and VGPRs); the select sits here, not at the load, which it would wait for
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) wcur[kc] = wnext[kc];
-        // everything this wave requested has landed (stage st of A, in LDS, included); past the barrier that holds for all four
+        for (int j = 0; j < KCW; ++j) wcur[j] = st * KC + kh * KCW + j < nkb ? wnext[j] : wraw_t{};
+        // everything this wave requested has landed (stage st of A, in LDS, included); past the barrier that holds for all
         // waves, and every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // the A fragments are read with ds_read_b128 issued from inline asm: a ds_read the compiler can see makes it drain vmcnt
         // first (the LDS-DMA of the NEXT stage might alias), which serialises the stage's memory latency with its MFMAs.
-        // Fragments of k-block kc + 1 are requested right before the MFMAs of k-block kc are issued.
-        const unsigned ab = lds_base + (unsigned)(buf * KC * MTW * 1024);
-        const int kcs = min(KC, nkb - st * KC);
+        // Fragments of the next k-block are requested before the MFMAs of the current one are issued.
+        const unsigned ab = lds_base + (unsigned)((buf * KC + kh * KCW) * MTW * 1024);
         f32x4 af[2][MTW];
         strip_read<MTW>(af[0], ab);
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            if (kc < kcs && !(S.dbg & 2)) {
-                strip_wait<MTW>(af[kc & 1]);
-                if (kc + 1 < KC && kc + 1 < kcs) strip_read<MTW>(af[(kc + 1) & 1], ab + (unsigned)((kc + 1) * MTW * 1024));
-                const float4 wv = w_f4(wcur[kc]);
+        for (int j = 0; j < KCW; ++j) {
+            strip_wait<MTW>(af[j & 1]);
+            if (j + 1 < KCW) strip_read<MTW>(af[(j + 1) & 1], ab + (unsigned)((j + 1) * MTW * 1024));
+            const float4 wv = w_f4(wcur[j]);
 #pragma unroll
-                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][0], wv.x, acc[t], 0, 0, 0);
+            for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][t][0], wv.x, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][1], wv.y, acc[t], 0, 0, 0);
+            for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][t][1], wv.y, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][2], wv.z, acc[t], 0, 0, 0);
+            for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][t][2], wv.z, acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kc & 1][t][3], wv.w, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][t][3], wv.w, acc[t], 0, 0, 0);
             // the next stage's requests go out behind the first k-block's MFMAs: their issue time is off the critical path
-            if (kc == 0 && st + 1 < nst && !(S.dbg & 1)) {
+            if (j == 0 && st + 1 < nst && !(S.dbg & 1)) {
                 stage_a(st + 1, buf ^ 1);
                 stage_w(st + 1);
             }
@@ -606,23 +607,37 @@ __global__ __launch_bounds__(256) void k_gemm_strip(const GemmArgs G, const Stri
     // Epilogue through LDS: a lane holds rows 4*(lane>>4) + q, column lane & 15 of each 16x16 tile -- 4-byte stores in 64-byte
     // row pieces, which the write path takes at under 1 TB/s.  The accumulators are laid out as the workgroup's
     // [16*MTW rows][64 columns] tile in LDS and go out as float4: rows of 256 contiguous bytes (four rows per wave store), or,
-    // for a fragment-major destination, each wave's own 16x16 tile as one contiguous 1 KiB block.
+    // for a fragment-major destination, a wave's 16x16 tile as one contiguous 1 KiB block.
     constexpr int LDT = 68;
     __syncthreads();                    // every wave is done with the stage buffers
     if (!(S.dbg & 4)) {
         float* T = strip_lds;
+        if (kh == 0) {
 #pragma unroll
-        for (int t = 0; t < MTW; ++t)
+            for (int t = 0; t < MTW; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) T[(t * 16 + 4 * (lane >> 4) + q) * LDT + wave * 16 + (lane & 15)] = acc[t][q];
+                for (int q = 0; q < 4; ++q) T[(t * 16 + 4 * (lane >> 4) + q) * LDT + wn * 16 + (lane & 15)] = acc[t][q];
+        }
+        if (KH > 1) {
+            __syncthreads();
+            if (kh == 1) {
+#pragma unroll
+                for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) T[(t * 16 + 4 * (lane >> 4) + q) * LDT + wn * 16 + (lane & 15)] += acc[t][q];
+            }
+        }
+        __syncthreads();
         const bool fm = S.SK == 1 && G.e.c_fm16;
-        if (!fm) __syncthreads();       // (a fragment-major store reads back only the wave's own columns)
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int row = fm ? (lane & 15) : wave * 4 + (lane >> 4);
-        const int col = fm ? wave * 16 + 4 * (lane >> 4) : 4 * (lane & 15);
+        // row-major: wave w stores rows w, w + NWV/... of every tile; fragment-major: wave (wn, kh) stores column tile wn of the
+        // tiles t with t % KH == kh
+        const int row = fm ? (lane & 15) : (wave * 4 + (lane >> 4)) & 15;
+        const int col = fm ? wn * 16 + 4 * (lane >> 4) : 4 * (lane & 15);
         const int n = nb * 64 + col;
+        const int t0 = fm ? kh : (wave * 4) >> 4;               // first tile of this wave's share, stride KH
 #pragma unroll
-        for (int t = 0; t < MTW; ++t) {
+        for (int tt = 0; tt < (MTW + KH - 1) / KH; ++tt) {
+            const int t = t0 + tt * KH;
             const int m = (t_lo + t) * 16 + row;
             if (t < nt && m < G.M) {
                 const float4 v = *reinterpret_cast<const float4*>(T + (t * 16 + row) * LDT + col);
@@ -678,8 +693,8 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
     static const size_t lds_floor = getenv("GVC_STRIP_LDS") ? (size_t)atoi(getenv("GVC_STRIP_LDS")) * 1024 : 0;
 #define GVC_STRIP(w)                                                                                                         \
     case w:                                                                                                                  \
-        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_strip<w, 1>), grid, dim3(256), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);              \
-        else hipLaunchKernelGGL((k_gemm_strip<w, 0>), grid, dim3(256), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);                       \
+        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_strip<w, 1, 2>), grid, dim3(512), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);              \
+        else hipLaunchKernelGGL((k_gemm_strip<w, 0, 2>), grid, dim3(512), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);                       \
         break;
     switch (best_w) { GVC_STRIP(1) GVC_STRIP(2) GVC_STRIP(3) GVC_STRIP(4) GVC_STRIP(5) GVC_STRIP(6) GVC_STRIP(7) GVC_STRIP(8) GVC_STRIP(9) }
 #undef GVC_STRIP
@@ -698,8 +713,8 @@ void gemm_init_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_skinny_ln<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 #define GVC_STRIP_ATTR(w)                                                                                                                      \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_strip<w, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     GVC_STRIP_ATTR(1) GVC_STRIP_ATTR(2) GVC_STRIP_ATTR(3) GVC_STRIP_ATTR(4) GVC_STRIP_ATTR(5) GVC_STRIP_ATTR(6) GVC_STRIP_ATTR(7) GVC_STRIP_ATTR(8) GVC_STRIP_ATTR(9)
 #undef GVC_STRIP_ATTR
 }
