@@ -496,10 +496,10 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
 // (one float4 per lane per k-block, requested a stage ahead) and keeps MTW independent 16x16 accumulators, so an A fragment
 // read from LDS feeds 4 MFMAs and a weight fragment 4*MTW.  Per k-block and wave: 1 global float4, MTW ds_read_b128,
 // 4*MTW v_mfma_f32_16x16x4_f32 (32 cycles each): the loop is bound by the MFMA pipe.
-struct StripGeom { int MG, NB, SK, mt, kb, dbg; };    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
+struct StripGeom { int MG, NB, SK, mt, kb, raw, dbg; };    // raw: partial planes go to G.work even when SK == 1    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
 
 template <int MTW> struct StripCfg {
-    static constexpr int KC = MTW >= 5 ? 4 : 8;                      // k-blocks per stage: <= 36 KiB of A per stage         // k-blocks per stage: <= 36 KiB of A per stage, two workgroups fit a CU
+    static constexpr int KC = MTW >= 5 ? 4 : 8;                      // k-blocks per stage: <= 36 KiB of A per stage
     static constexpr size_t stage_bytes = (size_t)2 * KC * MTW * 1024, tile_bytes = (size_t)MTW * 16 * 68 * 4;
     static constexpr size_t lds_bytes = stage_bytes > tile_bytes ? stage_bytes : tile_bytes;
 };
@@ -628,7 +628,8 @@ __global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const
             }
         }
         __syncthreads();
-        const bool fm = S.SK == 1 && G.e.c_fm16;
+        const bool part = S.SK > 1 || S.raw;
+        const bool fm = !part && G.e.c_fm16;
         // row-major: wave w stores rows w, w + NWV/... of every tile; fragment-major: wave (wn, kh) stores column tile wn of the
         // tiles t with t % KH == kh
         const int row = fm ? (lane & 15) : (wave * 4 + (lane >> 4)) & 15;
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const
             const int m = (t_lo + t) * 16 + row;
             if (t < nt && m < G.M) {
                 const float4 v = *reinterpret_cast<const float4*>(T + (t * 16 + row) * LDT + col);
-                if (S.SK > 1) *reinterpret_cast<float4*>(G.work + ((size_t)sk * G.M + m) * G.N + n) = v;
+                if (part) *reinterpret_cast<float4*>(G.work + ((size_t)sk * G.M + m) * G.N + n) = v;
                 else gemm_store4(G, m, n, v);
             }
         }
@@ -657,6 +658,7 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
                 "strip gemm: unsupported shape M=%d N=%d K=%d (FM16 operands, N %% 64 == 0, 16-byte rows)", G.M, G.N, G.K);
     StripGeom S;
     S.mt = cdiv(G.M, 16); S.NB = G.N / 64; S.kb = G.K / 16;
+    GVC_REQUIRE(!raw_partials || (G.work && (long long)G.M * G.N <= work_cap), GVC_ERR_ARG, "strip gemm: raw partials need a work buffer");
     if (!G.work) sk_max = 1;
     if (sk_max < 1) sk_max = 1;
     if (sk_max > 8) sk_max = 8;
@@ -687,6 +689,7 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
     S.MG = cdiv(S.mt, best_w); S.SK = best_sk;
     static const int dbg = getenv("GVC_STRIP_DBG") ? atoi(getenv("GVC_STRIP_DBG")) : 0;
     S.dbg = dbg;
+    S.raw = raw_partials && G.work ? 1 : 0;
     G.SK = best_sk;
     if (sk_used) *sk_used = best_sk;
     const dim3 grid(S.MG * S.NB * S.SK);
