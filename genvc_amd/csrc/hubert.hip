@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "gemm.h"
+#include <algorithm>
 
 namespace gvc {
 
@@ -320,8 +321,9 @@ struct gvc_hubert {
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
     int skinny = 1;                               // GVC_HUBERT_SKINNY=0: always the tiled GEMM in the transformer
+    int strip = 1;                                // GVC_HUBERT_STRIP=0: more than 128 rows go to the tiled GEMM
     bool fm_ready = false;                        // FM16 copies match the bound weights
-    float *xf = nullptr, *af = nullptr, *hf = nullptr;   // FM16 activations of the skinny path (128 rows)
+    float *xf = nullptr, *af = nullptr, *hf = nullptr;   // FM16 activations of the fragment-major path (all rows, 16-row tiles)
     std::vector<void*> allocs;
 };
 
@@ -415,14 +417,16 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
     if (!rc) rc = hb_alloc(c, &c->att, B * F * E);
     if (!rc) rc = hb_alloc(c, &c->qkv, B * F * 3 * E);
     if (!rc) rc = hb_alloc(c, &c->hbuf, B * F * D.ffn_dim);
-    if (!rc) rc = hb_alloc(c, &c->xf, (size_t)128 * E);
-    if (!rc) rc = hb_alloc(c, &c->af, (size_t)128 * E);
-    if (!rc) rc = hb_alloc(c, &c->hf, (size_t)128 * D.ffn_dim);
+    const size_t fm_rows = std::max<size_t>(128, (B * F + 15) & ~(size_t)15);      // fragment-major activations come in 16-row tiles
+    if (!rc) rc = hb_alloc(c, &c->xf, fm_rows * E);
+    if (!rc) rc = hb_alloc(c, &c->af, fm_rows * E);
+    if (!rc) rc = hb_alloc(c, &c->hf, fm_rows * D.ffn_dim);
     c->work_cap = 16ll << 20;
     if (!rc) rc = hb_alloc(c, &c->work, (size_t)c->work_cap);
     if (!rc && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = GVC_ERR_HIP;
     if (getenv("GVC_HUBERT_GRAPH")) c->use_graph = atoi(getenv("GVC_HUBERT_GRAPH"));
     if (getenv("GVC_HUBERT_SKINNY")) c->skinny = atoi(getenv("GVC_HUBERT_SKINNY"));
+    if (getenv("GVC_HUBERT_STRIP")) c->strip = atoi(getenv("GVC_HUBERT_STRIP"));
     if (E % 128 != 0 || D.ffn_dim % 128 != 0) c->skinny = 0;
     if (rc) { gvc_hubert_destroy(c); return rc; }
     *out = c;
@@ -584,23 +588,33 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
         G.e.resid = c->xp + b * xp_bs + (size_t)c->pad_front * E; G.e.ldr = E; G.e.resid_batch_stride = cg;
         if ((rc = launch_gemm_cap(G, D.pos_conv_groups, c->work_cap, s))) return rc;
     }
-    const bool skinny = c->skinny && rows <= 128;
+    const bool skinny = c->skinny && (rows <= 128 || (c->strip && E % 64 == 0 && D.ffn_dim % 64 == 0));
+    const bool strip = rows > 128;
     if (skinny) {
-        // rows <= 128 (the 1 s streaming chunk: 49 frames): fragment-major skinny GEMMs, K-split partials folded into the
-        // post-LN kernels: 7 launches per layer, weights streamed once
+        // fragment-major GEMMs, K-split partials folded into the post-LN kernels: 7 launches per layer.  rows <= 128 (the 1 s
+        // streaming chunk: 49 frames): the skinny kernels, weights streamed once; more rows (an utterance, a batch): the strip
+        // kernel, which picks its own K split
         hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,
                            c->enc_ln.w, c->enc_ln.b, (const float*)nullptr, 0, (const float*)nullptr, rows, c->xf);
         GVC_LAUNCH_CHECK();
+        int sk_used = 1;
         auto sk_gemm = [&](const HbLin& L, const float* A_fm, float* C, int act, int c_fm16, int SK, const float* resid = nullptr) {
             GemmArgs G;
             memset(&G, 0, sizeof(G));
             G.A = A_fm; G.lda = L.K; G.Wt = L.wf; G.ldw = L.K; G.C = C; G.ldc = L.N; G.M = rows; G.N = L.N; G.K = L.K;
             G.work = c->work;
+            if (strip && resid) {          // a projection back to E columns: raw partial planes, completed by the post-LN kernel
+                if ((long long)rows * L.N > c->work_cap) { set_error("hubert: %d rows exceed the split-K work buffer", rows); return (int)GVC_ERR_ARG; }
+                return launch_gemm_strip(G, 8, c->work_cap, 1, &sk_used, s);
+            }
+            sk_used = SK;
             if (SK == 1) { G.e.bias = L.b; G.e.act = act; G.e.c_fm16 = c_fm16; G.e.resid = resid; G.e.ldr = L.N; }
+            if (strip) return launch_gemm_strip(G, 1, c->work_cap, 0, nullptr, s);
             return launch_gemm_skinny(G, SK, c->work_cap, s);
         };
-        auto post_ln = [&](const HbLin& L, const HbLn& N, int SK) {       // x = LN(x + linear) (+ FM16 copy)
-            if (SK > 1)
+        auto post_ln = [&](const HbLin& L, const HbLn& N, int) {       // x = LN(x + linear) (+ FM16 copy)
+            const int SK = sk_used;
+            if (SK > 1 || strip)
                 hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->x, (long long)F * E, c->x, (long long)F * E, F, E,
                                    N.w, N.b, c->work, SK, L.b, rows, c->xf);
             else
