@@ -565,6 +565,11 @@ static GemvArgs base_args(gvc_gpt* c, const int32_t* slots, int row0) {
 }
 
 static int launch_attention(gvc_gpt* c, AttnArgs T, int chunks, int rows, bool direct, hipStream_t s, bool wide = false) {
+    // prefill-shaped calls (>= 16 rows per stream): 16-row query tiles on the matrix cores
+    int rc = GVC_OK;
+    if (direct && chunks == 1 && !wide && T.T >= 16 && rows % T.T == 0 &&
+        launch_attention_tile(c->hd, c->dm.n_head, T, rows / T.T, T.base_len ? c->dm.max_seq : T.T, s, c->kv_bf16 != 0, &rc))
+        return rc;
     return launch_attention_hd(c->hd, c->dm.n_head, T, chunks, rows, direct, s, wide && c->hd == 256, c->kv_bf16 != 0);
 }
 

@@ -652,6 +652,373 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefill attention on the matrix cores: one workgroup (8 waves) per (16 query rows, head, stream).
+// k_attention gives every (row, head) its own workgroup, so the K/V rows of a head are pulled through L2 once per
+// query row (240 MB per layer at 5 x 110 rows) and every key costs a wave reduction.  Here a tile of 16 query rows
+//   1. S = scale * Q K^T : the key tiles are shared out over the waves; Q fragments stay in registers, K fragments
+//      come straight from the cache rows (a float4 of 4 dims per lane), v_mfma_f32_16x16x4_f32; S lands in LDS;
+//   2. softmax per row in LDS (two rows per wave): p = exp(s - max), masked past the row's last key, and 1 / sum;
+//   3. O = P V : V is staged through LDS 64 keys at a time (requested a chunk ahead, coalesced key rows); every wave
+//      owns HD/128 column tiles of the head; the normalised tile leaves through LDS as float4 (row-major or FM16).
+// Same arithmetic as the reference's softmax(QK^T / sqrt(hd)) V (GPT2Attention._attn through
+// /root/reference/layers/gpt_inference.py:81-91); sums in MFMA order, within the tests' 1e-4 of the oracle.
+// ---------------------------------------------------------------------------------------------
+
+typedef float at_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int HD, int KVB, int VC>          // VC: keys per V chunk (128 when the whole context is one chunk, else 64)
+__global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nkp, int dbg) {
+    constexpr int KB = HD / 16;                    // 16-dim blocks of a head
+    constexpr int NTW = KB >= 8 ? KB / 8 : 1;      // output column tiles per wave
+    constexpr int LDV = HD + 4;
+    constexpr int ES = KVB ? 2 : 4;
+    constexpr int VPT = VC * (HD / 4) / 512;       // float4 of a V chunk per thread
+    extern __shared__ __attribute__((aligned(16))) float at_lds[];
+    const int lds_s = nkp + 4;
+    float* S = at_lds;                              // [16][lds_s]
+    float* linv = S + 16 * lds_s;                   // [16]
+    float* Vs = linv + 16;                          // [VC][LDV]; the output tile [16][LDV] afterwards
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int bi = A.slots ? A.slots[b] : b;
+    const int base = A.base_len ? A.base_len[bi] : 0;
+    const int nk = A.causal ? base + min(t0 + 16, A.T) : A.n_keys;       // keys any row of the tile sees
+    const int nkt = (nk + 15) >> 4;
+    const char* kp = reinterpret_cast<const char*>(A.kbase) + (bi * A.k_batch_stride + h * A.k_head_stride) * ES;
+    const char* vp = reinterpret_cast<const char*>(A.vbase) + (bi * A.k_batch_stride + h * A.k_head_stride) * ES;
+    const size_t krow = (size_t)A.k_row_stride * ES;
+
+    // the first V chunk is requested before anything else: it arrives under phases 1 and 2
+    typename KvRaw<KVB>::T vreg[VPT];
+    auto v_request = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 512 * i;
+            const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+            vreg[i] = load_kv_raw<KVB>(vp + (size_t)min(c0 + key, nk - 1) * krow + (size_t)d4 * 4 * ES);
+        }
+    };
+    auto v_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = tid + 512 * i;
+            const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+            *reinterpret_cast<float4*>(Vs + key * LDV + d4 * 4) = kv_f4(vreg[i]);
+        }
+    };
+    if (!(dbg & 16)) v_request(0);
+
+    // ---- 1. S = scale * Q K^T ----
+    float4 qf[KB];
+    {
+        const int t = min(t0 + r16, A.T - 1);
+        const float* qp = A.q + (size_t)(b * A.T + t) * A.q_stride + h * HD + 4 * g;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const float4*>(qp + kb * 16);
+    }
+    for (int kt = wave; kt < ((dbg & 1) ? 0 : nkt); kt += 8) {
+        const int key = min(kt * 16 + r16, nk - 1);
+        const char* kr = kp + (size_t)key * krow + (size_t)(4 * g) * ES;
+        typename KvRaw<KVB>::T kraw[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) kraw[kb] = load_kv_raw<KVB>(kr + (size_t)kb * 16 * ES);
+        at_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // (two chains: a dependent MFMA waits ~40 cycles)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float4 kf = kv_f4(kraw[kb]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kb].x, kf.x, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kb].y, kf.y, acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kb].z, kf.z, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kb].w, kf.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(4 * g + q) * lds_s + kt * 16 + r16] = (acc[q] + acc1[q]) * A.scale;
+    }
+    __syncthreads();
+
+    // ---- 2. softmax rows 2*wave, 2*wave + 1 ----
+#pragma unroll
+    for (int rr = 0; rr < ((dbg & 2) ? 0 : 2); ++rr) {
+        const int r = 2 * wave + rr;
+        const int lim = A.causal ? min(base + t0 + r + 1, nk) : nk;
+        float* sr = S + r * lds_s;
+        float mx = -INFINITY;
+        for (int k = lane; k < nkt * 16; k += 64) mx = fmaxf(mx, k < lim ? sr[k] : -INFINITY);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int k = lane; k < nkt * 16; k += 64) {
+            const float pr = k < lim ? __expf(sr[k] - mx) : 0.f;
+            sr[k] = pr;
+            sum += pr;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) linv[r] = 1.0f / sum;
+    }
+
+    // ---- 3. O = P V ----
+    at_f32x4 oacc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) oacc[i] = {0.f, 0.f, 0.f, 0.f};
+    const bool pv_wave = wave * NTW < KB;            // (HD = 64: four column tiles, waves 4..7 only help staging)
+    for (int c0 = 0; c0 < ((dbg & 4) ? 0 : nkt * 16); c0 += VC) {
+        __syncthreads();                             // the previous chunk is consumed (first pass: S is complete)
+        v_commit();
+        __syncthreads();
+        if (c0 + VC < nkt * 16) v_request(c0 + VC);
+        if (pv_wave) {
+#pragma unroll
+            for (int kb = 0; kb < VC / 16; ++kb) {
+                if (c0 + kb * 16 < nkt * 16) {
+                    const float4 pf = *reinterpret_cast<const float4*>(S + r16 * lds_s + c0 + kb * 16 + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < NTW; ++i) {
+                        const float* vcol = Vs + (kb * 16 + 4 * g) * LDV + (wave * NTW + i) * 16 + r16;
+                        oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vcol[0], oacc[i], 0, 0, 0);
+                        oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vcol[LDV], oacc[i], 0, 0, 0);
+                        oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vcol[2 * LDV], oacc[i], 0, 0, 0);
+                        oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vcol[3 * LDV], oacc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // the normalised tile, row-major in LDS, then float4 stores
+    float* Os = Vs;
+    if (pv_wave) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Os[(4 * g + q) * LDV + (wave * NTW + i) * 16 + r16] = oacc[i][q] * linv[4 * g + q];
+    }
+    __syncthreads();
+    if (dbg & 8) return;
+    if (A.out_fm16) {
+        // 16-dim block kb of the head: lane L carries slot L of the fragment-major block (row L & 15, dims 4 (L >> 4) ..)
+        for (int kb = wave; kb < KB; kb += 8) {
+            const int t = t0 + r16;
+            if (t < A.T) {
+                const float4 v = *reinterpret_cast<const float4*>(Os + r16 * LDV + kb * 16 + 4 * g);
+                const int m = b * A.T + t, k = h * HD + kb * 16 + 4 * g, K16 = A.out_stride >> 4;
+                *reinterpret_cast<float4*>(A.out + ((size_t)(m >> 4) * K16 + (k >> 4)) * 256 + (((m & 15) + 16 * ((k & 15) >> 2)) << 2)) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < 16 * (HD / 4); idx += 512) {
+            const int r = idx / (HD / 4), d4 = idx - r * (HD / 4);
+            if (t0 + r < A.T)
+                *reinterpret_cast<float4*>(A.out + (size_t)(b * A.T + t0 + r) * A.out_stride + h * HD + d4 * 4) =
+                    *reinterpret_cast<const float4*>(Os + r * LDV + d4 * 4);
+        }
+    }
+}
+
+// The common prefill case -- every row of the tile sees at most 128 keys (a segment's prefix without a cached context): Q, the
+// whole K and the whole V of the head are requested up front with coalesced row loads (one memory round trip for the kernel),
+// K and V take turns in one LDS buffer, and every fragment comes from LDS.  One key tile per wave in phase 1; the P V loop has
+// no tail case (S is zero-filled up to 128 keys).
+template <int HD, int KVB>
+__global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A, int dbg) {
+    constexpr int KB = HD / 16, NTW = KB >= 8 ? KB / 8 : 1, LDV = HD + 4, ES = KVB ? 2 : 4;
+    constexpr int NKP = 128, LDS_S = NKP + 4;
+    constexpr int KPT = NKP * (HD / 4) / 512;      // float4 of K (or V) per thread
+    constexpr int QPT = (16 * (HD / 4) + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) float at_lds[];
+    float* S = at_lds;                              // [16][LDS_S]
+    float* linv = S + 16 * LDS_S;                   // [16]
+    float* KV = linv + 16;                          // [128][LDV]: K, then V, then the output tile
+    float* Qs = KV + NKP * LDV;                     // [16][LDV]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int bi = A.slots ? A.slots[b] : b;
+    const int base = A.base_len ? A.base_len[bi] : 0;
+    const int nk = min(NKP, A.causal ? base + min(t0 + 16, A.T) : A.n_keys);
+    const int nkt = (nk + 15) >> 4;
+    const char* kp = reinterpret_cast<const char*>(A.kbase) + (bi * A.k_batch_stride + h * A.k_head_stride) * ES;
+    const char* vp = reinterpret_cast<const char*>(A.vbase) + (bi * A.k_batch_stride + h * A.k_head_stride) * ES;
+    const size_t krow = (size_t)A.k_row_stride * ES;
+
+    typename KvRaw<KVB>::T kreg[KPT], vreg[KPT];
+    float4 qreg[QPT];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 512 * i;
+        const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+        kreg[i] = load_kv_raw<KVB>(kp + (size_t)min(key, nk - 1) * krow + (size_t)d4 * 4 * ES);
+    }
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const int idx = tid + 512 * i;
+        const int r = min(idx / (HD / 4), 15), d4 = idx % (HD / 4);
+        qreg[i] = *reinterpret_cast<const float4*>(A.q + (size_t)(b * A.T + min(t0 + r, A.T - 1)) * A.q_stride + h * HD + d4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 512 * i;
+        const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+        vreg[i] = load_kv_raw<KVB>(vp + (size_t)min(key, nk - 1) * krow + (size_t)d4 * 4 * ES);
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 512 * i;
+        const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+        *reinterpret_cast<float4*>(KV + key * LDV + d4 * 4) = kv_f4(kreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const int idx = tid + 512 * i;
+        if (idx < 16 * (HD / 4)) *reinterpret_cast<float4*>(Qs + (idx / (HD / 4)) * LDV + (idx % (HD / 4)) * 4) = qreg[i];
+    }
+    __syncthreads();
+
+    // ---- 1. S = scale * Q K^T: key tile `wave` ----
+    if (wave < nkt && !(dbg & 1)) {
+        at_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // (two chains: a dependent MFMA waits ~40 cycles)
+        const float* qrow = Qs + r16 * LDV + 4 * g;
+        const float* krw = KV + (wave * 16 + r16) * LDV + 4 * g;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const float4 qf = *reinterpret_cast<const float4*>(qrow + kb * 16);
+            const float4 kf = *reinterpret_cast<const float4*>(krw + kb * 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.x, kf.x, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.y, kf.y, acc1, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.z, kf.z, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.w, kf.w, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(4 * g + q) * LDS_S + wave * 16 + r16] = (acc[q] + acc1[q]) * A.scale;
+    }
+    __syncthreads();                  // S complete; K is consumed
+
+    // ---- 2. V takes the buffer; softmax rows 2*wave, 2*wave + 1 (zero past the row's last key, up to 128) ----
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + 512 * i;
+        const int key = idx / (HD / 4), d4 = idx - key * (HD / 4);
+        *reinterpret_cast<float4*>(KV + key * LDV + d4 * 4) = kv_f4(vreg[i]);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + rr;
+        const int lim = A.causal ? min(base + t0 + r + 1, nk) : nk;
+        float* sr = S + r * LDS_S;
+        const float s0 = lane < lim ? sr[lane] : -INFINITY, s1 = lane + 64 < lim ? sr[lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(s0, s1));
+        const float p0 = lane < lim ? __expf(s0 - mx) : 0.f, p1 = lane + 64 < lim ? __expf(s1 - mx) : 0.f;
+        sr[lane] = p0;
+        sr[lane + 64] = p1;
+        const float sum = wave_sum(p0 + p1);
+        if (lane == 0) linv[r] = 1.0f / sum;
+    }
+    __syncthreads();
+
+    // ---- 3. O = P V ----
+    at_f32x4 oacc[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) oacc[i] = {0.f, 0.f, 0.f, 0.f};
+    const bool pv_wave = wave * NTW < KB;
+    if (pv_wave && !(dbg & 4)) {
+#pragma unroll
+        for (int kb = 0; kb < NKP / 16; ++kb) {
+            const float4 pf = *reinterpret_cast<const float4*>(S + r16 * LDS_S + kb * 16 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                const float* vcol = KV + (kb * 16 + 4 * g) * LDV + (wave * NTW + i) * 16 + r16;
+                oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, vcol[0], oacc[i], 0, 0, 0);
+                oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, vcol[LDV], oacc[i], 0, 0, 0);
+                oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, vcol[2 * LDV], oacc[i], 0, 0, 0);
+                oacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, vcol[3 * LDV], oacc[i], 0, 0, 0);
+            }
+        }
+    }
+    // the normalised tile goes out through the Q buffer (nobody reads Q any more): row-major in LDS, then float4 stores
+    float* Os = Qs;
+    if (pv_wave) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Os[(4 * g + q) * LDV + (wave * NTW + i) * 16 + r16] = oacc[i][q] * linv[4 * g + q];
+    }
+    __syncthreads();
+    if (A.out_fm16) {
+        for (int kb = wave; kb < KB; kb += 8) {
+            const int t = t0 + r16;
+            if (t < A.T) {
+                const float4 v = *reinterpret_cast<const float4*>(Os + r16 * LDV + kb * 16 + 4 * g);
+                const int m = b * A.T + t, k = h * HD + kb * 16 + 4 * g, K16 = A.out_stride >> 4;
+                *reinterpret_cast<float4*>(A.out + ((size_t)(m >> 4) * K16 + (k >> 4)) * 256 + (((m & 15) + 16 * ((k & 15) >> 2)) << 2)) = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < 16 * (HD / 4); idx += 512) {
+            const int r = idx / (HD / 4), d4 = idx - r * (HD / 4);
+            if (t0 + r < A.T)
+                *reinterpret_cast<float4*>(A.out + (size_t)(b * A.T + t0 + r) * A.out_stride + h * HD + d4 * 4) =
+                    *reinterpret_cast<const float4*>(Os + r * LDV + d4 * 4);
+        }
+    }
+}
+
+// launch when the call is a prefill-shaped causal/direct one (T >= 16 rows per stream); false: the caller uses k_attention
+static inline bool launch_attention_tile(int head_dim, int n_head, const AttnArgs& T, int batch, int max_keys, hipStream_t s,
+                                         bool kv_bf16, int* rc) {
+    static const int enabled = getenv("GVC_ATTN_TILE") ? atoi(getenv("GVC_ATTN_TILE")) : 1;
+    // (few tiles -- one stream's segment prefix -- leave most CUs idle behind one latency chain: k_attention's row-per-workgroup grid wins)
+    if (!enabled || T.T < 16 || batch * ((T.T + 15) / 16) < 12 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return false;
+    const int nkp = (max_keys + 15) & ~15;
+    static const int dbg = getenv("GVC_ATTN_DBG") ? atoi(getenv("GVC_ATTN_DBG")) : 0;
+    if (nkp <= 128) {
+        const size_t lds_short = ((size_t)16 * 132 + 16 + (size_t)(128 + 16) * (head_dim + 4)) * sizeof(float);
+        const dim3 grid_s((T.T + 15) / 16, n_head, batch);
+#define GVC_ATT_SHORT(hd, kvb)                                                                                                    \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_tile_short<hd, kvb>),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_attention_tile_short<hd, kvb>), grid_s, dim3(512), lds_short, s, T, dbg);                          \
+    }
+        if (head_dim == 256) { if (kv_bf16) GVC_ATT_SHORT(256, 1) else GVC_ATT_SHORT(256, 0) }
+        else if (head_dim == 128) { if (kv_bf16) GVC_ATT_SHORT(128, 1) else GVC_ATT_SHORT(128, 0) }
+        else { if (kv_bf16) GVC_ATT_SHORT(64, 1) else GVC_ATT_SHORT(64, 0) }
+#undef GVC_ATT_SHORT
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error("kernel launch failed: %s (attention tile)", hipGetErrorString(e)); *rc = GVC_ERR_HIP; return true; }
+        *rc = GVC_OK;
+        return true;
+    }
+    const int vc = 64;
+    const size_t lds = ((size_t)16 * (nkp + 4) + 16 + (size_t)vc * (head_dim + 4)) * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    const dim3 grid((T.T + 15) / 16, n_head, batch);
+#define GVC_ATT_TILE(hd, kvb)                                                                                                     \
+    {                                                                                                                             \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_tile<hd, kvb, 64>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_tile<hd, kvb, 128>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        if (vc == 128) hipLaunchKernelGGL((k_attention_tile<hd, kvb, 128>), grid, dim3(512), lds, s, T, nkp, dbg);                    \
+        else hipLaunchKernelGGL((k_attention_tile<hd, kvb, 64>), grid, dim3(512), lds, s, T, nkp, dbg);                               \
+    }
+    if (head_dim == 256) { if (kv_bf16) GVC_ATT_TILE(256, 1) else GVC_ATT_TILE(256, 0) }
+    else if (head_dim == 128) { if (kv_bf16) GVC_ATT_TILE(128, 1) else GVC_ATT_TILE(128, 0) }
+    else { if (kv_bf16) GVC_ATT_TILE(64, 1) else GVC_ATT_TILE(64, 0) }
+#undef GVC_ATT_TILE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("kernel launch failed: %s (attention tile)", hipGetErrorString(e)); *rc = GVC_ERR_HIP; return true; }
+    *rc = GVC_OK;
+    return true;
+}
+
 // host launcher shared by the GPT and Perceiver contexts
 static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& T, int chunks, int rows, bool direct,
                                       hipStream_t s, bool wide = false, bool kv_bf16 = false) {
