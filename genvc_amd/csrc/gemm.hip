@@ -496,7 +496,7 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
 // (one float4 per lane per k-block, requested a stage ahead) and keeps MTW independent 16x16 accumulators, so an A fragment
 // read from LDS feeds 4 MFMAs and a weight fragment 4*MTW.  Per k-block and wave: 1 global float4, MTW ds_read_b128,
 // 4*MTW v_mfma_f32_16x16x4_f32 (32 cycles each): the loop is bound by the MFMA pipe.
-struct StripGeom { int MG, NB, SK, mt, kb, raw, dbg; };    // raw: partial planes go to G.work even when SK == 1    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
+struct StripGeom { int MG, NB, SK, mt, kb, raw; };    // raw: partial planes go to G.work even when SK == 1    // m groups, n blocks, K splits, m tiles, k blocks of the whole problem
 
 template <int MTW> struct StripCfg {
     static constexpr int KC = MTW >= 5 ? 4 : 8;                      // k-blocks per stage: <= 36 KiB of A per stage
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const
 
     stage_a(0, 0);
     stage_w(0);
-    for (int st = 0; st < ((S.dbg & 8) ? 1 : nst); ++st) {
+    for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         // k-blocks past the end get zero weights, so that the k loop has no tail case (a branch around MFMAs makes the
         // accumulators commute between AGPRs and VGPRs); the select sits here, not at the load, which it would wait for
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const
 #pragma unroll
             for (int t = 0; t < MTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j & 1][t][3], wv.w, acc[t], 0, 0, 0);
             // the next stage's requests go out behind the first k-block's MFMAs: their issue time is off the critical path
-            if (j == 0 && st + 1 < nst && !(S.dbg & 1)) {
+            if (j == 0 && st + 1 < nst) {
                 stage_a(st + 1, buf ^ 1);
                 stage_w(st + 1);
             }
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256 * KH) void k_gemm_strip(const GemmArgs G, const
     // for a fragment-major destination, a wave's 16x16 tile as one contiguous 1 KiB block.
     constexpr int LDT = 68;
     __syncthreads();                    // every wave is done with the stage buffers
-    if (!(S.dbg & 4)) {
+    {
         float* T = strip_lds;
         if (kh == 0) {
 #pragma unroll
@@ -687,17 +687,14 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
     }
     GVC_REQUIRE(best_w > 0, GVC_ERR_ARG, "strip gemm: no geometry for M=%d N=%d K=%d", G.M, G.N, G.K);
     S.MG = cdiv(S.mt, best_w); S.SK = best_sk;
-    static const int dbg = getenv("GVC_STRIP_DBG") ? atoi(getenv("GVC_STRIP_DBG")) : 0;
-    S.dbg = dbg;
     S.raw = raw_partials && G.work ? 1 : 0;
     G.SK = best_sk;
     if (sk_used) *sk_used = best_sk;
     const dim3 grid(S.MG * S.NB * S.SK);
-    static const size_t lds_floor = getenv("GVC_STRIP_LDS") ? (size_t)atoi(getenv("GVC_STRIP_LDS")) * 1024 : 0;
 #define GVC_STRIP(w)                                                                                                         \
     case w:                                                                                                                  \
-        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_strip<w, 1, 2>), grid, dim3(512), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);              \
-        else hipLaunchKernelGGL((k_gemm_strip<w, 0, 2>), grid, dim3(512), std::max(lds_floor, StripCfg<w>::lds_bytes), s, G, S);                       \
+        if (G.w_bf16) hipLaunchKernelGGL((k_gemm_strip<w, 1, 2>), grid, dim3(512), StripCfg<w>::lds_bytes, s, G, S);              \
+        else hipLaunchKernelGGL((k_gemm_strip<w, 0, 2>), grid, dim3(512), StripCfg<w>::lds_bytes, s, G, S);                       \
         break;
     switch (best_w) { GVC_STRIP(1) GVC_STRIP(2) GVC_STRIP(3) GVC_STRIP(4) GVC_STRIP(5) GVC_STRIP(6) GVC_STRIP(7) GVC_STRIP(8) GVC_STRIP(9) }
 #undef GVC_STRIP

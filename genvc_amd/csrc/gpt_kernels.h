@@ -667,8 +667,8 @@ __global__ __launch_bounds__(512, 2) void k_attn_proj(const AttnProjArgs A) {
 
 typedef float at_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int HD, int KVB, int VC>          // VC: keys per V chunk (128 when the whole context is one chunk, else 64)
-__global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nkp, int dbg) {
+template <int HD, int KVB, int VC>          // VC: keys per V chunk
+__global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nkp) {
     constexpr int KB = HD / 16;                    // 16-dim blocks of a head
     constexpr int NTW = KB >= 8 ? KB / 8 : 1;      // output column tiles per wave
     constexpr int LDV = HD + 4;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
             *reinterpret_cast<float4*>(Vs + key * LDV + d4 * 4) = kv_f4(vreg[i]);
         }
     };
-    if (!(dbg & 16)) v_request(0);
+    v_request(0);
 
     // ---- 1. S = scale * Q K^T ----
     float4 qf[KB];
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const float4*>(qp + kb * 16);
     }
-    for (int kt = wave; kt < ((dbg & 1) ? 0 : nkt); kt += 8) {
+    for (int kt = wave; kt < nkt; kt += 8) {
         const int key = min(kt * 16 + r16, nk - 1);
         const char* kr = kp + (size_t)key * krow + (size_t)(4 * g) * ES;
         typename KvRaw<KVB>::T kraw[KB];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
 
     // ---- 2. softmax rows 2*wave, 2*wave + 1 ----
 #pragma unroll
-    for (int rr = 0; rr < ((dbg & 2) ? 0 : 2); ++rr) {
+    for (int rr = 0; rr < 2; ++rr) {
         const int r = 2 * wave + rr;
         const int lim = A.causal ? min(base + t0 + r + 1, nk) : nk;
         float* sr = S + r * lds_s;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
 #pragma unroll
     for (int i = 0; i < NTW; ++i) oacc[i] = {0.f, 0.f, 0.f, 0.f};
     const bool pv_wave = wave * NTW < KB;            // (HD = 64: four column tiles, waves 4..7 only help staging)
-    for (int c0 = 0; c0 < ((dbg & 4) ? 0 : nkt * 16); c0 += VC) {
+    for (int c0 = 0; c0 < nkt * 16; c0 += VC) {
         __syncthreads();                             // the previous chunk is consumed (first pass: S is complete)
         v_commit();
         __syncthreads();
@@ -794,7 +794,6 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
             for (int q = 0; q < 4; ++q) Os[(4 * g + q) * LDV + (wave * NTW + i) * 16 + r16] = oacc[i][q] * linv[4 * g + q];
     }
     __syncthreads();
-    if (dbg & 8) return;
     if (A.out_fm16) {
         // 16-dim block kb of the head: lane L carries slot L of the fragment-major block (row L & 15, dims 4 (L >> 4) ..)
         for (int kb = wave; kb < KB; kb += 8) {
@@ -820,7 +819,7 @@ __global__ __launch_bounds__(512) void k_attention_tile(const AttnArgs A, int nk
 // K and V take turns in one LDS buffer, and every fragment comes from LDS.  One key tile per wave in phase 1; the P V loop has
 // no tail case (S is zero-filled up to 128 keys).
 template <int HD, int KVB>
-__global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A, int dbg) {
+__global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A) {
     constexpr int KB = HD / 16, NTW = KB >= 8 ? KB / 8 : 1, LDV = HD + 4, ES = KVB ? 2 : 4;
     constexpr int NKP = 128, LDS_S = NKP + 4;
     constexpr int KPT = NKP * (HD / 4) / 512;      // float4 of K (or V) per thread
@@ -875,7 +874,7 @@ __global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A, 
     __syncthreads();
 
     // ---- 1. S = scale * Q K^T: key tile `wave` ----
-    if (wave < nkt && !(dbg & 1)) {
+    if (wave < nkt) {
         at_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // (two chains: a dependent MFMA waits ~40 cycles)
         const float* qrow = Qs + r16 * LDV + 4 * g;
         const float* krw = KV + (wave * 16 + r16) * LDV + 4 * g;
@@ -920,7 +919,7 @@ __global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A, 
 #pragma unroll
     for (int i = 0; i < NTW; ++i) oacc[i] = {0.f, 0.f, 0.f, 0.f};
     const bool pv_wave = wave * NTW < KB;
-    if (pv_wave && !(dbg & 4)) {
+    if (pv_wave) {
 #pragma unroll
         for (int kb = 0; kb < NKP / 16; ++kb) {
             const float4 pf = *reinterpret_cast<const float4*>(S + r16 * LDS_S + kb * 16 + 4 * g);
@@ -969,7 +968,6 @@ static inline bool launch_attention_tile(int head_dim, int n_head, const AttnArg
     // (few tiles -- one stream's segment prefix -- leave most CUs idle behind one latency chain: k_attention's row-per-workgroup grid wins)
     if (!enabled || T.T < 16 || batch * ((T.T + 15) / 16) < 12 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return false;
     const int nkp = (max_keys + 15) & ~15;
-    static const int dbg = getenv("GVC_ATTN_DBG") ? atoi(getenv("GVC_ATTN_DBG")) : 0;
     if (nkp <= 128) {
         const size_t lds_short = ((size_t)16 * 132 + 16 + (size_t)(128 + 16) * (head_dim + 4)) * sizeof(float);
         const dim3 grid_s((T.T + 15) / 16, n_head, batch);
@@ -981,7 +979,7 @@ static inline bool launch_attention_tile(int head_dim, int n_head, const AttnArg
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_attention_tile_short<hd, kvb>), grid_s, dim3(512), lds_short, s, T, dbg);                          \
+        hipLaunchKernelGGL((k_attention_tile_short<hd, kvb>), grid_s, dim3(512), lds_short, s, T);                          \
     }
         if (head_dim == 256) { if (kv_bf16) GVC_ATT_SHORT(256, 1) else GVC_ATT_SHORT(256, 0) }
         else if (head_dim == 128) { if (kv_bf16) GVC_ATT_SHORT(128, 1) else GVC_ATT_SHORT(128, 0) }
@@ -1002,12 +1000,9 @@ static inline bool launch_attention_tile(int head_dim, int n_head, const AttnArg
         if (!attr) {                                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_tile<hd, kvb, 64>),                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_tile<hd, kvb, 128>),                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
             attr = true;                                                                                                          \
         }                                                                                                                         \
-        if (vc == 128) hipLaunchKernelGGL((k_attention_tile<hd, kvb, 128>), grid, dim3(512), lds, s, T, nkp, dbg);                    \
-        else hipLaunchKernelGGL((k_attention_tile<hd, kvb, 64>), grid, dim3(512), lds, s, T, nkp, dbg);                               \
+        hipLaunchKernelGGL((k_attention_tile<hd, kvb, 64>), grid, dim3(512), lds, s, T, nkp);                                    \
     }
     if (head_dim == 256) { if (kv_bf16) GVC_ATT_TILE(256, 1) else GVC_ATT_TILE(256, 0) }
     else if (head_dim == 128) { if (kv_bf16) GVC_ATT_TILE(128, 1) else GVC_ATT_TILE(128, 0) }
