@@ -597,3 +597,41 @@ def test_one_launch_step_context_regimes_vs_oracle(Tc, n):
         np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4, err_msg=f"step {j} ({pe.shape[1] + 1 + j} cached positions)")
         np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=1e-4)
     _cache.clear()
+
+
+@pytest.mark.parametrize("d,H,L,Tc,mode", [(1024, 4, 2, 75, "fp32"), (512, 4, 2, 150, "fp32"), (512, 8, 2, 40, "bf16_kv"), (768, 3, 2, 150, "bf16_kv")],
+                         ids=["hd256_short", "hd128_long_context", "hd64_short_bf16_cache", "hd256_long_context_bf16_cache"])
+def test_batched_prefill_attention_tiles_vs_oracle(d, H, L, Tc, mode):
+    """prefill attention on 16-row query tiles (csrc/gpt_kernels.h k_attention_tile_short: <= 128 keys; k_attention_tile: longer
+    contexts and cached prefixes) -- six streams so that the tile kernels are the ones launched, ragged against the tile size
+    (Tc + 35 rows), head_dim 64 / 128 / 256, fp32 and bf16 caches: next-token logits and latents of the plain prefill and of the
+    prefill that continues 32 cached conditioning rows, against the oracle (softmax(QK^T/sqrt(hd))V of GPT2Attention)"""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    _cache.clear()
+    torch.cuda.empty_cache()
+    margs = dict(gcfg.TINY_MODEL_ARGS, gpt_layers=L, gpt_n_model_channels=d, gpt_n_heads=H)
+    dims = gcfg.gpt_dims(margs)
+    w = synth.make_weights(29, synth.gpt_weight_spec(dims), device="cuda")
+    eng = GptEngine(dims, max_slots=8, max_rows=2048, weight_dtype=mode)
+    eng.bind(w)
+    wc = {k: v.cpu() for k, v in w.items()}
+    if mode != "fp32":
+        wc = _round_bf16(wc)            # bf16_kv stores the weights in bf16 too: the oracle runs on the same rounded values
+    dims_o = dict(dims, kv_bf16=mode == "bf16_kv")
+    B = 6
+    cond = synth.uniform(29, "cond", (B, 32, d), 1.0)
+    codes = synth.integers(29, "codes", (B, Tc), 256)
+    pe, _ = O.compute_embeddings(wc, dims_o, cond, codes)
+    z, logits, _ = O.gpt_prefill(wc, dims_o, pe)
+    slots = torch.arange(B, device="cuda", dtype=torch.int32)
+    prefix = eng.prefix_embeddings(cond.cuda(), codes.cuda().int())
+    tol = 2e-3 if mode == "bf16_kv" else 1e-4
+    lg, lat = eng.prefill(slots, prefix)
+    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=tol)
+    np.testing.assert_allclose(lat.cpu().numpy(), z.numpy(), atol=tol)
+    # the same rows as a continuation of the cached conditioning prefix (per-slot base length 32 in the kernels)
+    lg2, lat2 = eng.prefill(slots, prefix, n_cached=32)
+    np.testing.assert_allclose(lg2.cpu().numpy(), logits.numpy(), atol=tol)
+    np.testing.assert_allclose(lat2.cpu().numpy(), z.numpy(), atol=tol)
+    eng.close()
