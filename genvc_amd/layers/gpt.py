@@ -195,6 +195,59 @@ class GPT(nn.Module):
         self.last_latents = st["lats"][:, :n]
         return toks[:, :n]
 
+    @torch.inference_mode()
+    def generate_groups(self, groups, **generate_kwargs):
+        """Several generate() calls decoded TOGETHER: groups = [(cond_latents [B_i, 32, d], text_inputs [B_i, Tc_i]), ...] with
+        different code lengths.  Each group is prefilled on its own (its rows share a prefix length) into its own KV slots; the
+        decode steps then run over all streams at once, so the weights stream once per step for the whole set.  Streams are
+        independent, so with deterministic decoding (top_k = 1) every group's result is what generate() returns for it (bit for
+        bit when both land on the same decode kernels, i.e. the rows path from 5 streams up; within float rounding otherwise);
+        with sampling the per-row random streams would be numbered differently, so that case runs the groups one after another.
+        Returns a list of int64 [B_i, n_i] (reference gpt.py:594-609 per group)."""
+        self._need_engine()
+        kw = dict(generate_kwargs)
+        greedy = kw.get("top_k", 0) == 1 or not kw.get("do_sample", True)
+        total = sum(int(t.shape[0]) for _, t in groups)
+        if not greedy or len(groups) == 1 or total > self.max_slots or kw.get("num_beams", 1) != 1:
+            return [self.generate(c, t, **dict(kw)) for c, t in groups]
+        group = kw.pop("group", 16)
+        dev = groups[0][1].device
+        max_new = kw.get("max_new_tokens") or self.max_gen_mel_tokens
+        prefixes = [self.engine.prefix_embeddings(c.to(torch.float32).contiguous(), t.to(torch.int32).contiguous()) for c, t in groups]
+        n0s = [int(p.shape[1]) + 1 for p in prefixes]
+        width = max(n0s) + max_new + 8
+        ids = torch.full((total, width), 1, device=dev, dtype=torch.int32)
+        ids_len = torch.empty(total, device=dev, dtype=torch.int32)
+        slots = torch.arange(total, device=dev, dtype=torch.int32)
+        row = 0
+        spans = []
+        for p, n0 in zip(prefixes, n0s):
+            b = int(p.shape[0])
+            ids[row:row + b, n0 - 1] = self.start_audio_token
+            ids_len[row:row + b] = n0
+            self.engine.prefill(slots[row:row + b].contiguous(), p, want_outputs=False)
+            spans.append((row, row + b))
+            row += b
+        finished = torch.zeros(total, device=dev, dtype=torch.int32)
+        toks = torch.full((total, max_new), self.stop_audio_token, device=dev, dtype=torch.int32)
+        lats = torch.empty(total, max_new, self.model_dim, device=dev, dtype=torch.float32)
+        samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
+                    top_p=kw.get("top_p", 1.0), top_k=1)
+        params = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
+        done = 0
+        while done < max_new:
+            n = min(group, max_new - done)
+            self.engine.generate(slots, ids, ids_len, finished, params, done, n, toks, lats, max_keys=max(n0s) + done + n)
+            done += n
+            if bool(finished.all().item()):
+                break
+        out = []
+        for lo, hi in spans:
+            t = toks[lo:hi, :done].long()
+            out.append(t[:, :self._stop_len(t)])
+        self.last_latents = None          # (per-group latents are not kept: the callers of this path want tokens)
+        return out
+
     def _stop_len(self, toks):
         """steps the reference loop runs: up to and including the step where the last row emits the stop token"""
         is_stop = toks == self.stop_audio_token

@@ -53,8 +53,9 @@ def _n_segments(n_samples, seg):
 @torch.inference_mode()
 def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg=None, **gen_kwargs):
     """Tokens of a micro-batch of utterances.  Segment s of the utterances that HAVE a segment s of the same length forms
-    one batched generate() call (same prefix length: all full segments of the batch, and equal-length tails); tails of other
-    lengths run in their own calls -- never padded, which would change the reference's result (inference_utils.py:43-50).
+    one class (same prefix length: all full segments of the batch, and equal-length tails), prefilled in one batched call;
+    tails of other lengths are classes of their own -- never padded, which would change the reference's result
+    (inference_utils.py:43-50).  The classes are then decoded together.
     Returns int32 [B, n_seg, max_len] padded with the stop token (also the rows of segments an utterance does not have)."""
     m = model
     stop = m.gpt.stop_audio_token
@@ -67,6 +68,9 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
     out = torch.full((B, n_seg, max_len), stop, dtype=torch.int32, device=m.device)
     kw = dict(_sampling_kwargs(m))
     kw.update(gen_kwargs)
+    # every (segment index, segment length) class of the micro-batch: content codes per class, then ONE decode over all of them
+    # (layers/gpt.py generate_groups: a decode step streams the weights once whatever the number of streams)
+    classes = []
     for s in range(n_seg):
         groups = {}
         for b, p in enumerate(per_utt):
@@ -76,8 +80,19 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
             wav = torch.cat([per_utt[b][s] for b in rows], 0)
             feat = m.content_extractor.extract_content_features(wav)
             codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
-            gen = m.gpt.generate(cond_latent.expand(len(rows), -1, -1).contiguous(), codes, **kw)
+            classes.append((s, rows, codes))
+    max_slots = getattr(m.gpt, "max_slots", 8)
+    i = 0
+    while i < len(classes):                  # as many classes per joint decode as the KV slots hold
+        j, n = i, 0
+        while j < len(classes) and n + len(classes[j][1]) <= max_slots:
+            n += len(classes[j][1])
+            j += 1
+        j = max(j, i + 1)
+        gens = m.gpt.generate_groups([(cond_latent.expand(len(rows), -1, -1).contiguous(), codes) for _, rows, codes in classes[i:j]], **kw)
+        for (s, rows, _), gen in zip(classes[i:j], gens):
             out[rows, s, :gen.shape[1]] = gen.to(torch.int32)
+        i = j
     return out
 
 

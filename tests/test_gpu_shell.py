@@ -369,3 +369,41 @@ def test_harness_generation_takes_the_short_context_decode_variant(persist, expe
         next(gen)
     assert g.engine.decode_variant() == (3 if persist == "1" else 1)
     g.engine.close()
+
+
+def test_generate_groups_equals_separate_generate_calls():
+    """layers/gpt.py generate_groups (the batched offline path, BASELINE configs[2]): classes of different code lengths are
+    prefilled one by one and decoded TOGETHER; streams are independent, so each class gets exactly the tokens its own
+    generate() call returns (reference gpt.py:594-609).  Classes of >= 5 streams, so that the joint and the separate calls
+    both decode on the rows path (a different kernel family could flip a near-tie); then the same through convert_batch."""
+    from genvc_amd.inference.model_init import model_init_synthetic
+    from genvc_amd.parallel_offline import convert_batch
+    _m.clear()
+    torch.cuda.empty_cache()
+    m = model_init_synthetic(gcfg.default_config(tiny=True), seed=5, device=DEV, max_slots=16)[0]
+    m.config.top_k = 1
+    d = m.gpt.model_dim
+    cond = synth.uniform(71, "cond", (1, 32, d), 1.0).to(DEV)
+    groups = []
+    for i, (B, Tc) in enumerate(((5, 40), (6, 25))):
+        groups.append((cond.expand(B, -1, -1).contiguous(), synth.integers(71 + i, "codes", (B, Tc), 256).to(DEV)))
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, repetition_penalty=2.0, do_sample=True, num_beams=1, max_new_tokens=20)
+    joint = m.gpt.generate_groups(groups, **kw)
+    sep = [m.gpt.generate(c, t, **kw) for c, t in groups]
+    for a, b in zip(joint, sep):
+        assert torch.equal(a, b), (a, b)
+    # sampling: the groups run one after another (the per-row random streams keep their numbering)
+    kw_s = dict(kw, top_k=15, seed=7)
+    for a, b in zip(m.gpt.generate_groups(groups, **kw_s), [m.gpt.generate(c, t, **kw_s) for c, t in groups]):
+        assert torch.equal(a, b)
+    # through the offline driver: six utterances of 2.5 s at seg_len 2 s -> a class of full segments and a class of 0.5 s tails
+    sr = m.content_sample_rate
+    wavs = [synth.synth_audio(300 + i, "src", int(2.5 * sr)) for i in range(6)]
+    both = convert_batch(m, wavs, cond, seg_len=2.0, max_new_tokens=16)
+    joint_fn = m.gpt.generate_groups
+    m.gpt.generate_groups = lambda gs, **k: [m.gpt.generate(c, t, **k) for c, t in gs]
+    try:
+        ref = convert_batch(m, wavs, cond, seg_len=2.0, max_new_tokens=16)
+    finally:
+        m.gpt.generate_groups = joint_fn
+    assert both.shape == ref.shape and both.shape[:2] == (6, 2) and torch.equal(both, ref)

@@ -234,6 +234,9 @@ class _StubModel:
             base = (codes.sum(1, keepdim=True) + (cond[0].sum() * 1000).long()) % 1000
             return (base + torch.arange(n)[None, :]) % 1024
 
+        def generate_groups(self, groups, **kw):                             # the real one decodes the groups together
+            return [self.generate(c, t, **kw) for c, t in groups]
+
     content_extractor, content_dvae = _Extractor(), _Dvae()
 
     def __init__(self):
