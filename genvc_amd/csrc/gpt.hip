@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "gemm.h"
+#include <algorithm>
 #include "gpt_kernels.h"
 #include "persist_kernel.h"
 #include "sampler.h"
@@ -216,6 +217,7 @@ struct gvc_gpt {
     int* seam_err_dev = nullptr;
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int strip_prefill = 1;                        // GVC_STRIP_PREFILL=0: more than 128 rows go to the tiled GEMM
+    int fuse_ln_rows = 8;                         // GVC_FUSE_LN_ROWS: the prologue variant serves up to this many rows (<= 16)
     int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
     float* xalt = nullptr;                        // second residual buffer of that path [16][d]
     int rows_decode_min = 5;                      // batches of at least this many streams decode on the MFMA rows path (0: never);
@@ -291,6 +293,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     c->n_expected = 10 + 12 * (int)L;
     if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
     if (getenv("GVC_FUSE_LN")) c->fuse_ln = atoi(getenv("GVC_FUSE_LN"));
+    if (getenv("GVC_FUSE_LN_ROWS")) c->fuse_ln_rows = std::min(16, std::max(1, atoi(getenv("GVC_FUSE_LN_ROWS"))));
     if (getenv("GVC_STRIP_PREFILL")) c->strip_prefill = atoi(getenv("GVC_STRIP_PREFILL"));
     gemm_init_attributes();
     GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
@@ -847,7 +850,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
     // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
     // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
-    if (skinny && rows <= 16 && c->fuse_ln) {
+    if (skinny && rows <= c->fuse_ln_rows && c->fuse_ln) {
         float* X[2] = {c->x, c->xalt};
         int cur = 0;
         for (int l = 0; l < c->dm.n_layer; ++l) {
