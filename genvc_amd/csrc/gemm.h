@@ -50,6 +50,10 @@ struct GemmArgs {
     // (tap = k / conv_cin, ci = k % conv_cin) and lives at A[m*lda + tap*conv_tap_stride + ci]
     int conv_cin, conv_tap_stride;
     int a_act; float a_slope;       // GemmAAct applied to A elements as they are loaded
+    // skinny kernels, <= 32 rows: A = the batched decode attention's per-chunk softmax partials, merged while the fragments are
+    // loaded (att_part [M][att_heads][att_nc][att_hd + 4] = (o[hd], m, l, pad) as k_attention<.., DIRECT = false> writes them;
+    // K = att_heads * att_hd); null: A is the FM16 operand
+    const float* att_part; int att_nc, att_heads, att_hd;
     int SK;                  // split-K factor; >1: C unused, partials to `work`
     float* work;             // [batch][SK][M][N]
     GemmEpi e;

@@ -146,7 +146,7 @@ __device__ __forceinline__ float4 w_f4(const uint2& u) {
                        __uint_as_float(u.y & 0xffff0000u));
 }
 
-template <int MT, int NW, int WB = 0>
+template <int MT, int NW, int WB = 0, int NC = 0>          // NC > 0: A is merged from NC attention chunk partials (G.att_part)
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     extern __shared__ __attribute__((aligned(16))) float red_raw[];     // [NW][MT][256]
     float (*red)[MT][256] = reinterpret_cast<float (*)[MT][256]>(red_raw);
@@ -155,7 +155,6 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     const int n0 = blockIdx.x * 16;
     const int kslice = G.K / G.SK;                 // per workgroup
     const int kw = kslice / NW;                    // per wave, multiple of 16
-    (void)r; (void)g;
     const int kb16 = (blockIdx.y * kslice + wave * kw) >> 4;       // first 16-wide k block of this wave
     const int K16 = G.K >> 4;
     typedef typename WRaw<WB>::T wraw_t;
@@ -169,18 +168,73 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     for (int t = 0; t < MT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
     // all fragment loads of a batch are issued before the first MFMA; a batch is sized to ~32 float4 per lane
     // (the whole K range of a wave for the GenVC shapes), so a wave pays one memory round trip
-    constexpr int U = 32 / (1 + MT) >= 8 ? 8 : (32 / (1 + MT) >= 4 ? 4 : 2);
+    constexpr int U = NC > 0 ? (32 / (MT * NC) >= 8 ? 8 : 32 / (MT * NC)) : (32 / (1 + MT) >= 8 ? 8 : (32 / (1 + MT) >= 4 ? 4 : 2));
+    // NC > 0: the wave's K range lies inside one head (att_hd % kw == 0), so the merge weights exp(m_c - M) / L of a row are
+    // computed once per wave and M tile; a fragment is sum_c weight_c * o_c
+    float wn[MT][NC > 0 ? NC : 1], mc[MT][NC > 0 ? NC : 1], lc[MT][NC > 0 ? NC : 1];
+    const float* pp[MT];
+    if constexpr (NC > 0) {
+        const int kg = blockIdx.y * kslice + wave * kw;              // first k of this wave
+        const int h = kg / G.att_hd, pstride = G.att_hd + 4;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int row = min(t * 16 + r, G.M - 1);
+            pp[t] = G.att_part + ((size_t)(row * G.att_heads + h) * NC) * pstride;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { mc[t][c] = pp[t][c * pstride + G.att_hd]; lc[t][c] = pp[t][c * pstride + G.att_hd + 1]; }
+            pp[t] += (kg - h * G.att_hd) + 4 * g;                    // this lane's four dims of k-block 0
+        }
+    }
     for (int ks = 0; ks < kw; ks += 16 * U) {
         wraw_t wr[U];
         float4 a4[U][MT];
+        float4 oc[NC > 0 ? U : 1][MT][NC > 0 ? NC : 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = ks + 16 * u;
             const bool kin = k < kw;                   // rows past M hold stale data: their results are never stored
             wr[u] = kin ? wp[k * 4] : wraw_t{};
+            if constexpr (NC > 0) {
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
-                a4[u][t] = kin ? *reinterpret_cast<const float4*>(ap[t] + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        oc[u][t][c] = *reinterpret_cast<const float4*>(pp[t] + c * (G.att_hd + 4) + (kin ? k : 0));
+            } else {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    a4[u][t] = kin ? *reinterpret_cast<const float4*>(ap[t] + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (NC > 0) {
+            if (ks == 0) {           // (after the first batch of requests has gone out: the (m, l) pairs arrive ahead of it)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float mx = mc[t][0];
+#pragma unroll
+                    for (int c = 1; c < NC; ++c) mx = fmaxf(mx, mc[t][c]);
+                    float L = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) { wn[t][c] = __expf(mc[t][c] - mx); L += wn[t][c] * lc[t][c]; }
+                    const float inv = 1.0f / L;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) wn[t][c] *= inv;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ks + 16 * u < kw) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            o.x += wn[t][c] * oc[u][t][c].x; o.y += wn[t][c] * oc[u][t][c].y;
+                            o.z += wn[t][c] * oc[u][t][c].z; o.w += wn[t][c] * oc[u][t][c].w;
+                        }
+                    }
+                    a4[u][t] = o;
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -476,6 +530,19 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
     dim3 grid(G.N / 16, SK);
     const bool w8 = (G.K / SK) % 128 == 0;           // 8 waves when every wave still gets whole 16-wide k steps
     const size_t lds = (size_t)(w8 ? 8 : 4) * MT * 256 * sizeof(float);
+    if (G.att_part) {            // A merged from the batched decode attention's chunk partials
+        GVC_REQUIRE(w8 && MT <= 2 && (G.att_nc == 2 || G.att_nc == 4) && G.att_heads * G.att_hd == G.K && G.att_hd % (G.K / SK / 8) == 0 &&
+                        G.att_hd % 4 == 0, GVC_ERR_ARG, "skinny gemm: attention-partial operand needs <= 32 rows, 2 or 4 chunks (M=%d chunks=%d)", G.M, G.att_nc);
+#define GVC_SKINNY_ATT(mt, nc)                                                                                   \
+        if (MT == mt && G.att_nc == nc) {                                                                          \
+            if (G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny<mt, 8, 1, nc>), grid, dim3(512), lds, s, G);           \
+            else hipLaunchKernelGGL((k_gemm_skinny<mt, 8, 0, nc>), grid, dim3(512), lds, s, G);                    \
+        }
+        GVC_SKINNY_ATT(1, 2) GVC_SKINNY_ATT(1, 4) GVC_SKINNY_ATT(2, 2) GVC_SKINNY_ATT(2, 4)
+#undef GVC_SKINNY_ATT
+        GVC_LAUNCH_CHECK();
+        return GVC_OK;
+    }
 #define GVC_SKINNY(mt)                                                                               \
     case mt:                                                                                         \
         if (w8 && G.w_bf16) hipLaunchKernelGGL((k_gemm_skinny<mt, 8, 1>), grid, dim3(512), lds, s, G); \

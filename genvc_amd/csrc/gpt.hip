@@ -752,7 +752,7 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
     return launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, B, s);
 }
 
-static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len = nullptr);
+static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len = nullptr, int key_chunks = 1);
 
 // Batched decode step on the MFMA path: the B new rows go through the skinny fragment-major GEMMs (weights streamed
 // once for up to 128 streams) instead of the 8-stream GEMV groups.  Same arithmetic as a prefill of one row per stream
@@ -763,12 +763,12 @@ static bool rows_decode_ok(const gvc_gpt* c, int B) {
 }
 
 static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* tok_in, float* logits_out, float* latent_out,
-                       int32_t* step_ctr, hipStream_t s) {
+                       int32_t* step_ctr, hipStream_t s, int key_chunks = 1) {
     const int d = c->dm.d_model;
     int rc;
     hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d);
     GVC_LAUNCH_CHECK();
-    if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len))) return rc;
+    if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len, key_chunks))) return rc;
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         GemvArgs A = base_args(c, slots + g, g);
@@ -839,7 +839,7 @@ extern "C" int gvc_gpt_prefix_embeddings(gvc_gpt* c, const float* cond, int32_t 
 // rows <= 128 (a streaming prefill): skinny MFMA GEMMs; the N = d projections are K-split over 4 workgroup
 // rows and their raw partial sums are folded into the NEXT LayerNorm launch (k_ln_sum_rows), so a layer is
 // 7 launches.  Larger row counts (batched offline prefill, latent re-pass) use the tiled GEMM.
-static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len) {
+static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len, int key_chunks) {
     const int d = c->dm.d_model, rows = B * T;
     int rc;
     const bool skinny = c->skinny_prefill && c->wfm && rows <= 128 && d % 256 == 0 && (long long)4 * rows * d <= c->work_cap / 2;
@@ -847,6 +847,10 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
     float* part_proj = c->work;                                    // [SKP][rows][d]
     float* part_p2 = c->work + c->work_cap / 2;                    // [SKP][rows][d]
     int ln_rc = GVC_OK;          // (a lambda cannot return through GVC_REQUIRE: the first failure is kept and returned below)
+    // batched decode over long contexts (key_chunks > 1, from the caller's key bound): the keys of a (stream, head) are split over
+    // 2 or 4 workgroups of k_attention and the chunk partials are merged while the attn c_proj GEMM loads its A fragments
+    const int att_nc = (skinny && base_len && T == 1 && rows <= 32 && c->hd == 256 && (key_chunks == 2 || key_chunks == 4) &&
+                        rows <= c->dm.max_slots) ? key_chunks : 1;
     // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
     // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
@@ -873,10 +877,14 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
             AttnArgs At = gpt_attn_args(c, l, slots);
             At.q = c->q; At.T = T; At.base_len = base_len;
             At.out = c->a; At.out_stride = d; At.out_fm16 = 1;
-            if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
+            if (att_nc > 1) {
+                At.out = c->part;
+                if ((rc = launch_attention(c, At, att_nc, rows, false, s, true))) return rc;
+            } else if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
             memset(&G, 0, sizeof(G));
             G.A = c->a; G.lda = d; G.Wt = ly.proj_f; G.w_bf16 = c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d; G.work = part_proj;
+            if (att_nc > 1) { G.att_part = c->part; G.att_nc = att_nc; G.att_heads = c->dm.n_head; G.att_hd = c->hd; }
             if ((rc = launch_gemm_skinny(G, SKP, c->work_cap / 2, s))) return rc;
 
             memset(&G, 0, sizeof(G));
@@ -933,12 +941,16 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
         At.q = c->q; At.T = T; At.base_len = base_len;
         At.out = c->a; At.out_stride = d; At.out_fm16 = fm ? 1 : 0;
         // one new row per cached stream (batched decode): 16 waves share the keys of a (row, head)
-        if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
+        if (att_nc > 1) {
+            At.out = c->part;
+            if ((rc = launch_attention(c, At, att_nc, rows, false, s, true))) return rc;
+        } else if ((rc = launch_attention(c, At, 1, rows, true, s, base_len && T == 1))) return rc;
 
         memset(&G, 0, sizeof(G));
         G.A = c->a; G.lda = d; G.Wt = fm ? ly.proj_f : ly.proj_w; G.w_bf16 = fm && c->bf16; G.ldw = d; G.C = c->x; G.ldc = d; G.M = rows; G.N = d; G.K = d;
         if (fm) {
             G.work = part_proj;
+            if (att_nc > 1) { G.att_part = c->part; G.att_nc = att_nc; G.att_heads = c->dm.n_head; G.att_hd = c->hd; }
             if ((rc = gemm_fm(G, strip ? 8 : SKP, 1, &sk_proj))) return rc;
             ln_sum_sk(part_proj, sk_proj, ly.proj_b, ly.ln2_w, ly.ln2_b);
         } else {
@@ -1041,7 +1053,7 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
 // ---------------------------------------------------------------------------------------------
 // generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
 // ---------------------------------------------------------------------------------------------
-static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) {
+static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, hipGraphExec_t* out) {
     hipStream_t cs = c->cap_stream;
     int rc = GVC_OK;
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
@@ -1049,7 +1061,7 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, hipGraphExec_t* out) 
     if (rc == GVC_OK && persist_ok(c, B))
         rc = launch_persist(c, c->gen_call->slots, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
     else if (rc == GVC_OK && rows_decode_ok(c, B))
-        rc = decode_rows(c, c->gen_call->slots, B, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
+        rc = decode_rows(c, c->gen_call->slots, B, c->tok_buf, c->logits, c->latent, c->step_ctr, cs, key_chunks);
     else
     for (int g = 0; g < B && rc == GVC_OK; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
@@ -1095,13 +1107,18 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 0);
     GVC_LAUNCH_CHECK();
     const bool fused = fused_ok(c, B, key_bound);
-    const int key = B * 2 + (fused ? 1 : 0);          // (rows mode and the one-launch step are pure functions of B: same key)
+    // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
+    // cached positions on (default 144; 0: never), four beyond 320
+    static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
+    const int key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
+                               ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
+    const int key = B * 2 + (fused ? 1 : 0) + 4096 * key_chunks;          // (the one-launch step is a pure function of B)
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     c->last_variant = persist_ok(c, B) ? 3 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;
-        if ((rc = build_step_graph(c, B, fused, &ge))) return rc;
+        if ((rc = build_step_graph(c, B, fused, key_chunks, &ge))) return rc;
         it = c->graphs.emplace(key, ge).first;
     }
     for (int i = 0; i < n_steps; ++i) GVC_CHECK_HIP(hipGraphLaunch(it->second, s));

@@ -1021,6 +1021,7 @@ static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& 
     dim3 block(256);
     if (kv_bf16 && head_dim == 256) {
         if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16, 1>), grid, dim3(1024), 0, s, T);
+        else if (wide) hipLaunchKernelGGL((k_attention<256, false, 16, 1>), grid, dim3(1024), 0, s, T);
         else if (direct) hipLaunchKernelGGL((k_attention<256, true, 4, 1>), grid, block, 0, s, T);
         else hipLaunchKernelGGL((k_attention<256, false, 4, 1>), grid, block, 0, s, T);
     } else if (kv_bf16 && head_dim == 64) {
@@ -1028,6 +1029,7 @@ static inline int launch_attention_hd(int head_dim, int n_head, const AttnArgs& 
         else hipLaunchKernelGGL((k_attention<64, false, 4, 1>), grid, block, 0, s, T);
     } else if (head_dim == 256) {
         if (direct && wide) hipLaunchKernelGGL((k_attention<256, true, 16>), grid, dim3(1024), 0, s, T);
+        else if (wide) hipLaunchKernelGGL((k_attention<256, false, 16>), grid, dim3(1024), 0, s, T);
         else if (direct) hipLaunchKernelGGL((k_attention<256, true>), grid, block, 0, s, T);
         else hipLaunchKernelGGL((k_attention<256, false>), grid, block, 0, s, T);
     } else if (head_dim == 64) {

@@ -635,3 +635,41 @@ def test_batched_prefill_attention_tiles_vs_oracle(d, H, L, Tc, mode):
     np.testing.assert_allclose(lg2.cpu().numpy(), logits.numpy(), atol=tol)
     np.testing.assert_allclose(lat2.cpu().numpy(), z.numpy(), atol=tol)
     eng.close()
+
+
+@pytest.mark.parametrize("B,Tc,n", [(6, 150, 40), (12, 150, 24), (6, 300, 24), (20, 300, 16)],
+                         ids=["8rows_2chunks", "16rows_2chunks", "8rows_4chunks", "32rows_4chunks"])
+def test_rows_mode_long_context_key_split_vs_oracle(B, Tc, n):
+    """batched decode over long contexts: the keys of a (stream, head) are split over 2 (> 144 cached positions) or 4 (> 320)
+    workgroups of k_attention and the chunk partials (o, m, l) are merged while the attn c_proj GEMM loads its A fragments
+    (csrc/gemm.hip k_gemm_skinny NC > 0) -- head_dim 256 (d = 512, two heads), with the fused-LayerNorm step (<= 8 rows), the
+    seven-launch step (9..16 rows) and two M tiles; greedy ids against the oracle wherever its own top-1/top-2 margin is not at
+    rounding level, latents to 2e-4 before the first flip"""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    _cache.clear()
+    torch.cuda.empty_cache()
+    margs = dict(gcfg.TINY_MODEL_ARGS, gpt_layers=2, gpt_n_model_channels=512, gpt_n_heads=2)
+    dims = gcfg.gpt_dims(margs)
+    w = synth.make_weights(31, synth.gpt_weight_spec(dims), device="cuda")
+    eng = GptEngine(dims, max_slots=max(B, 8), max_rows=8192)
+    eng.bind(w)
+    wc = {k: v.cpu() for k, v in w.items()}
+    cond = synth.uniform(31, "cond", (B, 32, 512), 1.0)
+    codes = synth.integers(31, "codes", (B, Tc), 256)
+    _, toks, lats = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() == 4                      # the rows path
+    ref_t, ref_l, ref_logits = O.generate(wc, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    pen = [O.process_logits(ref_logits[i], torch.cat([torch.ones(B, 32 + Tc + 2, dtype=torch.long),
+                                                       torch.full((B, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
+           for i in range(n)]
+    margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)
+    agree = toks.long() == ref_t
+    for b in range(B):
+        bad = (~agree[b]).nonzero()
+        if len(bad):
+            assert float(margins[b, int(bad[0])]) < 1e-3, (b, int(bad[0]), float(margins[b, int(bad[0])]))
+    assert agree.float().mean() > 0.9
+    first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
+    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-4)
+    eng.close()
