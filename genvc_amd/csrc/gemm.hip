@@ -800,6 +800,10 @@ extern "C" int gvc_gemm_probe(int32_t variant, const float* A, const float* W, c
     const int Mp = (M + 15) & ~15;
     float *Af = nullptr, *Wf = nullptr, *work = nullptr;
     const long long work_cap = (long long)8 * M * N;
+    struct Scratch {            // freed on every return path
+        float **a, **b, **c;
+        ~Scratch() { for (float** p : {a, b, c}) if (*p) (void)hipFree(*p); }
+    } scratch{&Af, &Wf, &work};
     GVC_CHECK_HIP(hipMalloc((void**)&work, (size_t)work_cap * sizeof(float)));
     GemmArgs G;
     memset(&G, 0, sizeof(G));
@@ -832,9 +836,6 @@ extern "C" int gvc_gemm_probe(int32_t variant, const float* A, const float* W, c
         *avg_us = ms * 1000.f / (float)iters;
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
-    hipStreamSynchronize(s);
-    hipFree(work);
-    if (Af) hipFree(Af);
-    if (Wf) hipFree(Wf);
+    (void)hipStreamSynchronize(s);
     return rc;
 }
