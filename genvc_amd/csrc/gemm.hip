@@ -255,18 +255,40 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[wave][t][q * 64 + lane] = acc[t][q];
     __syncthreads();
-    // thread (q, lane) finishes element row 16t + 4*(lane>>4) + q, column n0 + (lane & 15); tiles are shared out
-    // over the workgroup's thread quads
-    const int q = (tid >> 6) & 3;
-    const int n = n0 + (lane & 15);
-    for (int t = tid >> 8; t < MT; t += NW / 4) {
-        const int m = 16 * t + 4 * (lane >> 4) + q;
-        float v = 0.f;
+    // a thread finishes FOUR consecutive columns of one row (the four accumulator slots sit next to each other in `red`) and
+    // stores them as one float4: a row-major destination gets the tile as 16 rows x 64 bytes, an FM16 destination as its
+    // contiguous 1 KiB block (4-byte stores in 16-64 byte pieces are what the write path is slowest at).  Per element the waves'
+    // partial sums are still added in wave order.
+    if constexpr (MT <= 2) {    // one or two tiles: a thread per element (512 threads) finishes sooner than 64-128 threads with a float4 each
+        const int q = (tid >> 6) & 3;
+        const int n = n0 + (lane & 15);
+        for (int t = tid >> 8; t < MT; t += NW / 4) {
+            const int m = 16 * t + 4 * (lane >> 4) + q;
+            float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[w][t][q * 64 + lane];
+            for (int w = 0; w < NW; ++w) v += red[w][t][q * 64 + lane];
+            if (m < G.M) {
+                if (G.SK > 1) G.work[((size_t)blockIdx.y * G.M + m) * G.N + n] = v;
+                else gemm_store(G, 0, m, n, v);
+            }
+        }
+        return;
+    }
+    const bool fm = G.SK == 1 && G.e.c_fm16;
+    for (int item = tid; item < MT * 64; item += NW * 64) {
+        const int t = item >> 6, j = item & 63;
+        const int rr = fm ? (j & 15) : (j >> 2), k4 = fm ? (j >> 4) : (j & 3);
+        const int idx = (rr & 3) * 64 + (rr >> 2) * 16 + 4 * k4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float4 p = *reinterpret_cast<const float4*>(&red[w][t][idx]);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int m = 16 * t + rr, n = n0 + 4 * k4;
         if (m < G.M) {
-            if (G.SK > 1) G.work[((size_t)blockIdx.y * G.M + m) * G.N + n] = v;
-            else gemm_store(G, 0, m, n, v);
+            if (G.SK > 1) *reinterpret_cast<float4*>(G.work + ((size_t)blockIdx.y * G.M + m) * G.N + n) = v;
+            else gemm_store4(G, m, n, v);
         }
     }
 }
@@ -493,7 +515,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[wave][q * 64 + lane] = acc[q];
     __syncthreads();
-    if (tid < 256) {
+    if (tid < 256) {            // (one 16x16 tile: 256 threads with one element each finish sooner than 64 with a float4)
         const int q = tid >> 6;
         const int m = 4 * (lane >> 4) + q, n = n0 + (lane & 15);
         float v = 0.f;
@@ -504,7 +526,8 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
 }
 
 int launch_gemm_skinny_ln(GemmArgs G, const LnFuse& P, hipStream_t s) {
-    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && G.K % 256 == 0 && G.K >= 256 && G.K <= 1024 && (!P.part || P.SK == 4), GVC_ERR_ARG,
+    GVC_REQUIRE(G.M >= 1 && G.M <= 16 && P.rows == G.M && G.N % 16 == 0 && G.K % 256 == 0 && G.K >= 256 && G.K <= 1024 && (!P.part || P.SK == 4) &&
+                    G.ldc % 4 == 0 && (!G.e.qkv || (G.e.d % 16 == 0 && G.e.head_dim % 4 == 0)), GVC_ERR_ARG,
                 "skinny gemm + LN: unsupported shape M=%d N=%d K=%d", G.M, G.N, G.K);
     G.SK = 1;
     const size_t lds = ((size_t)16 * G.K + 8 * 256) * sizeof(float);
@@ -526,6 +549,8 @@ int launch_gemm_skinny(GemmArgs G, int SK, long long work_cap, hipStream_t s) {
                 "skinny gemm: unsupported shape M=%d N=%d K=%d SK=%d", G.M, G.N, G.K, SK);
     GVC_REQUIRE(SK == 1 || (G.work && (long long)SK * G.M * G.N <= work_cap), GVC_ERR_ARG, "skinny gemm: work buffer too small");
     GVC_REQUIRE(G.conv_cin == 0 && G.a_act == 0 && G.K % 16 == 0, GVC_ERR_ARG, "skinny gemm: FM16 operands only");
+    GVC_REQUIRE(G.ldc % 4 == 0 && (!G.e.resid || G.e.ldr % 4 == 0) && (!G.e.qkv || (G.e.d % 16 == 0 && G.e.head_dim % 4 == 0)), GVC_ERR_ARG,
+                "skinny gemm: rows must be 16-byte aligned (ldc=%d)", G.ldc);
     G.SK = SK;
     dim3 grid(G.N / 16, SK);
     const bool w8 = (G.K / SK) % 128 == 0;           // 8 waves when every wave still gets whole 16-wide k steps
