@@ -185,6 +185,50 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
             pp[t] += (kg - h * G.att_hd) + 4 * g;                    // this lane's four dims of k-block 0
         }
     }
+    if constexpr (NC == 0 && MT >= 4) {
+        // 4+ M tiles: a whole K range does not fit one batch of requests.  Two-k-block batches, double-buffered: the next batch
+        // is requested before the MFMAs of the current one are issued, so the memory round trips hide under the matrix work
+        constexpr int UB = 2;
+        wraw_t w0[UB], w1[UB];
+        float4 a0[UB][MT], a1[UB][MT];
+        auto request = [&](int ks, wraw_t (&wr)[UB], float4 (&a4)[UB][MT]) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int k = min(ks + 16 * u, kw - 16);           // (kw is a multiple of 32 on every caller's path; clamped anyway)
+                wr[u] = wp[k * 4];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) a4[u][t] = *reinterpret_cast<const float4*>(ap[t] + k * 16);
+            }
+        };
+        auto multiply = [&](int ks, const wraw_t (&wr)[UB], const float4 (&a4)[UB][MT]) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                float4 w4 = w_f4(wr[u]);
+                if (ks + 16 * u >= kw) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].x, w4.x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].y, w4.y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].z, w4.z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u][t].w, w4.w, acc[t], 0, 0, 0);
+            }
+        };
+        // (sched_barrier: left alone, the scheduler sinks every load to just above its first use -- least registers, no overlap)
+        request(0, w0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < kw; ks += 32 * UB) {
+            request(ks + 16 * UB, w1, a1);             // (past the end: the last block again, multiplied by zero weights)
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(ks, w0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            request(ks + 32 * UB, w0, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(ks + 16 * UB, w1, a1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
     for (int ks = 0; ks < kw; ks += 16 * U) {
         wraw_t wr[U];
         float4 a4[U][MT];

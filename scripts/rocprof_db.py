@@ -10,8 +10,10 @@ for db in dbs:
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    q = (f"select s.kernel_name, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), sum(d.end-d.start) "
-         f"from {disp} d join {sym} s on d.kernel_id=s.id group by s.kernel_name order by 6 desc")
+    by_grid = len(sys.argv) > 3 and sys.argv[3] == "grid"          # also split by launch geometry (the same kernel at different shapes)
+    name = "s.kernel_name || ' grid ' || d.grid_size_x || 'x' || d.grid_size_y" if by_grid else "s.kernel_name"
+    q = (f"select {name}, count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), sum(d.end-d.start) "
+         f"from {disp} d join {sym} s on d.kernel_id=s.id group by 1 order by 6 desc")
     rows = list(c.execute(q))
     total = sum(r[5] for r in rows)
     print(f"{db}: {total / 1e3:.1f} us of kernel time")
