@@ -140,6 +140,91 @@ __device__ __forceinline__ void gemm_store4(const GemmArgs& G, int m, int n, flo
     *reinterpret_cast<float4*>(G.C + (size_t)m * G.ldc + n) = v;
 }
 
+// The loads an epilogue needs that do not depend on the result -- bias, and for the QKV scatter the row's slot and cached
+// length (a chain of two) -- requested BEFORE the main loop by the thread that will store the element: left in gemm_store
+// they are three dependent L2 round trips behind the last MFMA.  (m < M; batch 0.)
+struct EpiPre { float4 bias; int slot, base; };
+__device__ __forceinline__ EpiPre gemm_prefetch(const GemmArgs& G, int m, int n, bool four) {
+    EpiPre p;
+    p.bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    p.slot = 0; p.base = 0;
+    if (G.e.bias) {
+        if (four) p.bias = *reinterpret_cast<const float4*>(G.e.bias + n);
+        else p.bias.x = G.e.bias[n];
+    }
+    if (G.e.qkv && n >= G.e.d) {
+        p.slot = G.e.slots[m / G.e.T];
+        p.base = G.e.base_len ? G.e.base_len[p.slot] : 0;
+    }
+    return p;
+}
+// gemm_store / gemm_store4 with the prefetched values
+__device__ __forceinline__ void gemm_store_pre(const GemmArgs& G, int m, int n, float v, const EpiPre& p) {
+    const GemmEpi& e = G.e;
+    v += p.bias.x;
+    if (e.act == ACT_GELU_NEW) v = gelu_new(v);
+    else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (e.act == ACT_GELU_ERF) v = gelu_erf(v);
+    if (e.qkv) {
+        const int which = n / e.d;
+        const int c = n - which * e.d;
+        if (which == 0) {
+            G.C[(size_t)m * G.ldc + c] = v;
+        } else {
+            const int b = m / e.T, t = m - b * e.T;
+            const int h = c / e.head_dim, j = c - h * e.head_dim;
+            float* cache = which == 1 ? e.kcache : e.vcache;
+            const size_t at = (((size_t)p.slot * e.n_head + h) * e.max_seq + (t + p.base)) * e.head_dim + j;
+            if (e.kv_bf16) reinterpret_cast<unsigned short*>(cache)[at] = f32_to_bf16(v);
+            else cache[at] = v;
+        }
+        return;
+    }
+    if (e.resid) v += e.resid[(size_t)m * e.ldr + n];
+    if (e.resid2) v += e.resid2[(size_t)m * e.ldr + n];
+    if (e.out_scale != 0.f) v *= e.out_scale;
+    if (e.c_fm16) { G.C[fm16_index(m, n, G.N)] = v; return; }
+    G.C[(size_t)m * G.ldc + n] = v;
+}
+__device__ __forceinline__ void gemm_store4_pre(const GemmArgs& G, int m, int n, float4 v, const EpiPre& p) {
+    const GemmEpi& e = G.e;
+    v.x += p.bias.x; v.y += p.bias.y; v.z += p.bias.z; v.w += p.bias.w;
+    if (e.act == ACT_GELU_NEW) { v.x = gelu_new(v.x); v.y = gelu_new(v.y); v.z = gelu_new(v.z); v.w = gelu_new(v.w); }
+    else if (e.act == ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (e.act == ACT_GELU_ERF) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    if (e.qkv) {
+        const int which = n / e.d;
+        const int c = n - which * e.d;
+        if (which == 0) {
+            *reinterpret_cast<float4*>(G.C + (size_t)m * G.ldc + c) = v;
+        } else {
+            const int b = m / e.T, t = m - b * e.T;
+            const int h = c / e.head_dim, j = c - h * e.head_dim;
+            float* cache = which == 1 ? e.kcache : e.vcache;
+            const size_t at = (((size_t)p.slot * e.n_head + h) * e.max_seq + (t + p.base)) * e.head_dim + j;
+            if (e.kv_bf16) {
+                ushort4 o;
+                o.x = f32_to_bf16(v.x); o.y = f32_to_bf16(v.y); o.z = f32_to_bf16(v.z); o.w = f32_to_bf16(v.w);
+                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(cache) + at) = o;
+            } else {
+                *reinterpret_cast<float4*>(cache + at) = v;
+            }
+        }
+        return;
+    }
+    if (e.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(e.resid + (size_t)m * e.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (e.resid2) {
+        const float4 r = *reinterpret_cast<const float4*>(e.resid2 + (size_t)m * e.ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (e.out_scale != 0.f) { v.x *= e.out_scale; v.y *= e.out_scale; v.z *= e.out_scale; v.w *= e.out_scale; }
+    if (e.c_fm16) { *reinterpret_cast<float4*>(G.C + fm16_index(m, n, G.N)) = v; return; }
+    *reinterpret_cast<float4*>(G.C + (size_t)m * G.ldc + n) = v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G);

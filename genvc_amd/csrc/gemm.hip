@@ -166,6 +166,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+    // what the epilogue of THIS thread will need besides the sums (see gemm_prefetch): same element mapping as below
+    EpiPre pre;
+    {
+        int pm, pn;
+        bool four = false;
+        if constexpr (MT <= 2) {
+            pm = 16 * (tid >> 8) + 4 * (lane >> 4) + ((tid >> 6) & 3); pn = n0 + (lane & 15);
+        } else {
+            const bool pfm = G.SK == 1 && G.e.c_fm16;
+            const int pt = tid >> 6, pj = tid & 63;
+            pm = 16 * pt + (pfm ? (pj & 15) : (pj >> 2)); pn = n0 + 4 * (pfm ? (pj >> 4) : (pj & 3));
+            four = true;
+        }
+        if (G.SK == 1) pre = gemm_prefetch(G, min(pm, G.M - 1), pn, four);
+    }
     // all fragment loads of a batch are issued before the first MFMA; a batch is sized to ~32 float4 per lane
     // (the whole K range of a wave for the GenVC shapes), so a wave pays one memory round trip
     constexpr int U = NC > 0 ? (32 / (MT * NC) >= 8 ? 8 : 32 / (MT * NC)) : (32 / (1 + MT) >= 8 ? 8 : (32 / (1 + MT) >= 4 ? 4 : 2));
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
             for (int w = 0; w < NW; ++w) v += red[w][t][q * 64 + lane];
             if (m < G.M) {
                 if (G.SK > 1) G.work[((size_t)blockIdx.y * G.M + m) * G.N + n] = v;
-                else gemm_store(G, 0, m, n, v);
+                else gemm_store_pre(G, m, n, v, pre);
             }
         }
         return;
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
         const int m = 16 * t + rr, n = n0 + 4 * k4;
         if (m < G.M) {
             if (G.SK > 1) *reinterpret_cast<float4*>(G.work + ((size_t)blockIdx.y * G.M + m) * G.N + n) = v;
-            else gemm_store4(G, m, n, v);
+            else gemm_store4_pre(G, m, n, v, pre);
         }
     }
 }
@@ -542,6 +557,8 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
     typedef typename WRaw<WB>::T wraw_t;
     wraw_t w4[U];
     const wraw_t* wp = reinterpret_cast<const wraw_t*>(G.Wt) + ((size_t)(n0 >> 4) * K16 + (wave * kw >> 4)) * 64 + lane;
+    EpiPre pre;                 // bias / slot / cached length of the element this thread stores at the end (gemm_prefetch)
+    if (tid < 256) pre = gemm_prefetch(G, min(4 * (lane >> 4) + (tid >> 6), G.M - 1), n0 + (lane & 15), false);
     if (P.part) skinny_ln_prologue<NV, true, wraw_t, U>(P, wp, w4, wave, lane, blockIdx.x == 0, a_lds);
     else skinny_ln_prologue<NV, false, wraw_t, U>(P, wp, w4, wave, lane, blockIdx.x == 0, a_lds);
     __syncthreads();
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(512) void k_gemm_skinny_ln(const GemmArgs G, const 
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][q * 64 + lane];
-        if (m < G.M) gemm_store(G, 0, m, n, v);
+        if (m < G.M) gemm_store_pre(G, m, n, v, pre);
     }
 }
 
