@@ -498,6 +498,8 @@ __global__ __launch_bounds__(NW * 64) void k_attention(const AttnArgs A) {
             kv[u] = load_kv_raw<KVB>(kp + off);
             vv[u] = load_kv_raw<KVB>(vp + off);
         }
+        // (left alone, the scheduler sinks the V requests below the score phase: a second memory round trip per pass)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float d = dot4(q4, kv_f4(kv[u]));
