@@ -218,7 +218,7 @@ struct gvc_gpt {
     int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
     int strip_prefill = 1;                        // GVC_STRIP_PREFILL=0: more than 128 rows go to the tiled GEMM
     int fuse_ln_rows = 8;                         // GVC_FUSE_LN_ROWS: the prologue variant serves up to this many rows (<= 16)
-    int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches stay separate on the <= 16-row skinny path
+    int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches always stay separate on the skinny path
     float* xalt = nullptr;                        // second residual buffer of that path [16][d]
     int rows_decode_min = 5;                      // batches of at least this many streams decode on the MFMA rows path (0: never);
                                                   // measured crossover: B=4 925 (GEMV) vs 975 us (rows), B=5 1242 vs 996 us
@@ -851,7 +851,8 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
     // 2 or 4 workgroups of k_attention and the chunk partials are merged while the attn c_proj GEMM loads its A fragments
     const int att_nc = (skinny && base_len && T == 1 && rows <= 32 && c->hd == 256 && (key_chunks == 2 || key_chunks == 4) &&
                         rows <= c->dm.max_slots) ? key_chunks : 1;
-    // <= 16 rows (a cached streaming prefill, a batched decode step of <= 16 streams): the row completion + LayerNorm runs
+    // <= fuse_ln_rows rows (8: a batched decode step of <= 8 streams; beyond, the prologue's L2 traffic -- rows x 6 planes in every
+    // workgroup -- costs more than the two launches it saves): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
     // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
     if (skinny && rows <= c->fuse_ln_rows && c->fuse_ln) {
