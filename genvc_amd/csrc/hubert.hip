@@ -356,6 +356,7 @@ extern "C" int gvc_hubert_frames(gvc_hubert* c, int32_t n_samples) {
 
 extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) {
     GVC_REQUIRE(dims && out, GVC_ERR_ARG, "gvc_hubert_create: null argument");
+    gemm_init_attributes();            // the strip GEMM's dynamic LDS (up to 72 KiB) needs the raised limit in a process without a GPT context too
     const gvc_hubert_dims& D = *dims;
     GVC_REQUIRE(D.n_conv >= 2 && D.n_conv <= 8 && D.conv_kernel[0] <= 16, GVC_ERR_UNSUPPORTED, "hubert: need 2..8 conv layers, k0 <= 16");
     for (int i = 0; i < D.n_conv; ++i)
