@@ -119,11 +119,16 @@ static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, lon
         v[i] = k < d ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (part && k < d) {
             const float4 b4 = *reinterpret_cast<const float4*>(pbias + k);
+            // the partial planes are requested together (a loop with a run-time trip count made each one its own round trip);
+            // added in plane order, as before
+            float4 p4[8];
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx)
+                p4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + ((size_t)sidx * rows + row) * d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
             v[i].x += b4.x; v[i].y += b4.y; v[i].z += b4.z; v[i].w += b4.w;
-            for (int sidx = 0; sidx < SK; ++sidx) {
-                const float4 p4 = *reinterpret_cast<const float4*>(part + ((size_t)sidx * rows + row) * d + k);
-                v[i].x += p4.x; v[i].y += p4.y; v[i].z += p4.z; v[i].w += p4.w;
-            }
+#pragma unroll
+            for (int sidx = 0; sidx < 8; ++sidx)
+                if (sidx < SK) { v[i].x += p4[sidx].x; v[i].y += p4[sidx].y; v[i].z += p4[sidx].z; v[i].w += p4[sidx].w; }
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
