@@ -410,17 +410,22 @@ __device__ __forceinline__ void row_finish(const RowOps<NV>& r, const float* par
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) { v[i].x += r.p[i][sidx].x; v[i].y += r.p[i][sidx].y; v[i].z += r.p[i][sidx].z; v[i].w += r.p[i][sidx].w; }
             } else {
+                // up to 8 planes (the strip GEMM's K split), requested together: a loop with a run-time trip count made every
+                // plane a round trip of its own; added in plane order
                 const int k = (i * 64 + lane) * 4;
-                for (int sidx = 0; sidx < SK; ++sidx) {
-                    const float4 q4 = *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k);
-                    v[i].x += q4.x; v[i].y += q4.y; v[i].z += q4.z; v[i].w += q4.w;
-                }
+                float4 q4[8];
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx)
+                    q4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sidx = 0; sidx < 8; ++sidx)
+                    if (sidx < SK) { v[i].x += q4[sidx].x; v[i].y += q4[sidx].y; v[i].z += q4[sidx].z; v[i].w += q4[sidx].w; }
             }
         }
     }
 }
 
-// SK is 4 on every caller's path (wave-uniform branches); the general case loops
+// SK = 4: the skinny path's split (wave-uniform branches); other splits (<= 8 planes) come from the strip GEMM
 template <int NV>
 __device__ __forceinline__ void row_sum(const float* xr, const float* part, size_t prow, size_t pstride, int SK, const float* bias,
                                         int lane, float4 (&v)[NV]) {
