@@ -128,6 +128,7 @@ struct ConvSmallArgs {
 };
 
 typedef float hf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hf_f32x4 __attribute__((ext_vector_type(4)));
 
 template <int C, int NW>
 __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
@@ -146,12 +147,27 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
     const int pad = A.dil * (A.k - 1) / 2;
     const size_t bs = (size_t)(A.T + 2 * kHfPad) * C;
     const float* xb = A.x + b * bs + (size_t)(kHfPad + t0 - pad) * C;
-    for (int i = tid; i < R * (C / 4); i += NTH) {
-        const int r = i / (C / 4), c4 = (i % (C / 4)) * 4;
-        float4 v = *reinterpret_cast<const float4*>(xb + (size_t)r * C + c4);
-        v.x = v.x > 0.f ? v.x : v.x * A.slope; v.y = v.y > 0.f ? v.y : v.y * A.slope;
-        v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
-        *reinterpret_cast<float4*>(&Xs[r * XS + c4]) = v;
+    // staging loops: UL requests per thread go out before the first LDS store (with a run-time trip count and one float4 per
+    // iteration the compiler emitted load / s_waitcnt vmcnt(0) / ds_write, a memory round trip per float4)
+    constexpr int UL = 8;
+    for (int i0 = tid; i0 < R * (C / 4); i0 += NTH * UL) {
+        float4 xv[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int i = min(i0 + u * NTH, R * (C / 4) - 1);
+            xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)(i / (C / 4)) * C + (i % (C / 4)) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink every request to just above its store)
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int i = i0 + u * NTH;
+            if (i < R * (C / 4)) {
+                float4 v = xv[u];
+                v.x = v.x > 0.f ? v.x : v.x * A.slope; v.y = v.y > 0.f ? v.y : v.y * A.slope;
+                v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
+                *reinterpret_cast<float4*>(&Xs[(i / (C / 4)) * XS + (i % (C / 4)) * 4]) = v;
+            }
+        }
     }
     hf_f32x16 acc;
 #pragma unroll
@@ -160,9 +176,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
     for (int tap0 = 0; tap0 < A.k; tap0 += tc) {
         const int nt = min(tc, A.k - tap0), kc4 = nt * C / 4;
         if (tap0 > 0) __syncthreads();             // the previous chunk of W has been consumed
-        for (int i = tid; i < 32 * kc4; i += NTH) {
-            const int n = i / kc4, k4 = (i % kc4) * 4;
-            *reinterpret_cast<float4*>(&Ws[n * WS + k4]) = *reinterpret_cast<const float4*>(A.w + (size_t)(n0 + n) * K + tap0 * C + k4);
+        // wave w stages rows w, w + NW, ... of the weight tile; the 32 / NW row requests of a column step go out together
+        constexpr int WR = 32 / NW;
+        for (int kk = lane; kk < kc4; kk += 64) {
+            hf_f32x4 wv[WR];
+#pragma unroll
+            for (int j = 0; j < WR; ++j)
+                wv[j] = *reinterpret_cast<const hf_f32x4*>(A.w + (size_t)(n0 + wave + NW * j) * K + tap0 * C + kk * 4);
+            __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink every request to just above its store)
+#pragma unroll
+            for (int j = 0; j < WR; ++j) *reinterpret_cast<hf_f32x4*>(&Ws[(wave + NW * j) * WS + kk * 4]) = wv[j];
         }
         __syncthreads();
         const int steps = nt * (C / 8);
@@ -183,17 +206,29 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
     // thread (wave, lane) finishes accumulator registers wave*16/NW .. of the tile
     constexpr int RPW = 16 / NW;
     const size_t ob = b * bs + (size_t)(kHfPad + t0) * C;
+    // bias and residuals of this thread's outputs are requested together, ahead of the LDS sums
+    const int n = n0 + (lane & 31);
+    const float bn = A.b[n];
+    float r1[RPW], r2[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        const size_t o = ob + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C + n;
+        r1[rr] = A.resid ? A.resid[o] : 0.f;
+        r2[rr] = A.resid2 ? A.resid2[o] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
         const int r = wave * RPW + rr;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[(w * 16 + r) * 64 + lane];
-        const int mo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = n0 + (lane & 31);
+        const int mo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const size_t o = ob + (size_t)mo * C + n;
-        v += A.b[n];
-        if (A.resid) v += A.resid[o];
-        if (A.resid2) v += A.resid2[o];
+        v += bn;
+        if (A.resid) v += r1[rr];
+        if (A.resid2) v += r2[rr];
         if (A.out_scale != 0.f) v *= A.out_scale;
         A.y[o] = v;
     }
