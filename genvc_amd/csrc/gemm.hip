@@ -35,10 +35,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
                 aoff = (size_t)m * G.lda + (size_t)tap * G.conv_tap_stride + (k - tap * G.conv_cin);
             }
             ra[j] = (m < G.M && k < kend) ? *reinterpret_cast<const float4*>(Ab + aoff) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (G.a_act == AACT_LRELU) {
-                ra[j].x = ra[j].x > 0.f ? ra[j].x : ra[j].x * G.a_slope; ra[j].y = ra[j].y > 0.f ? ra[j].y : ra[j].y * G.a_slope;
-                ra[j].z = ra[j].z > 0.f ? ra[j].z : ra[j].z * G.a_slope; ra[j].w = ra[j].w > 0.f ? ra[j].w : ra[j].w * G.a_slope;
-            }
             rb[j] = (n < G.N && k < kend) ? *reinterpret_cast<const float4*>(Wb + (size_t)n * G.ldw + k)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -48,6 +44,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + 256 * j;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
+            if (G.a_act == AACT_LRELU) {        // (applied where the tile is staged, a k step after its request: next to the load it waited for it)
+                ra[j].x = ra[j].x > 0.f ? ra[j].x : ra[j].x * G.a_slope; ra[j].y = ra[j].y > 0.f ? ra[j].y : ra[j].y * G.a_slope;
+                ra[j].z = ra[j].z > 0.f ? ra[j].z : ra[j].z * G.a_slope; ra[j].w = ra[j].w > 0.f ? ra[j].w : ra[j].w * G.a_slope;
+            }
             *reinterpret_cast<float4*>(&As[buf][r * LDL + c4]) = ra[j];
             *reinterpret_cast<float4*>(&Bs[buf][r * LDL + c4]) = rb[j];
         }
