@@ -416,7 +416,7 @@ __device__ __forceinline__ void row_finish(const RowOps<NV>& r, const float* par
                 float4 q4[8];
 #pragma unroll
                 for (int sidx = 0; sidx < 8; ++sidx)
-                    q4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + sidx * pstride + prow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    q4[sidx] = *reinterpret_cast<const float4*>(part + min(sidx, SK - 1) * pstride + prow + k);       // (clamped, not predicated: branches would serialise the requests)
 #pragma unroll
                 for (int sidx = 0; sidx < 8; ++sidx)
                     if (sidx < SK) { v[i].x += q4[sidx].x; v[i].y += q4[sidx].y; v[i].z += q4[sidx].z; v[i].w += q4[sidx].w; }

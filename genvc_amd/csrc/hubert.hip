@@ -124,7 +124,7 @@ static __global__ __launch_bounds__(256) void k_hb_ln_rows(const float* src, lon
             float4 p4[8];
 #pragma unroll
             for (int sidx = 0; sidx < 8; ++sidx)
-                p4[sidx] = sidx < SK ? *reinterpret_cast<const float4*>(part + ((size_t)sidx * rows + row) * d + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                p4[sidx] = *reinterpret_cast<const float4*>(part + ((size_t)min(sidx, SK - 1) * rows + row) * d + k);       // (clamped, not predicated: a branch per plane would serialise the requests again)
             v[i].x += b4.x; v[i].y += b4.y; v[i].z += b4.z; v[i].w += b4.w;
 #pragma unroll
             for (int sidx = 0; sidx < 8; ++sidx)
