@@ -99,8 +99,15 @@ __global__ void k_splitk_epilogue(const GemmArgs G) {
     const size_t mn = (size_t)G.M * G.N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (size_t)gridDim.x * blockDim.x) {
         const float* w = G.work + (size_t)batch * G.SK * mn + i;
+        // the SK <= 16 planes are requested together (clamped index; a loop with a run-time trip count was a round trip per plane)
+        // and added in plane order
+        float pv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pv[s] = w[(size_t)min(s, G.SK - 1) * mn];
         float v = 0.f;
-        for (int s = 0; s < G.SK; ++s) v += w[(size_t)s * mn];
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < G.SK) v += pv[s];
         gemm_store(G, batch, (int)(i / G.N), (int)(i % G.N), v);
     }
 }
