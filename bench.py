@@ -51,6 +51,7 @@ KERNEL_NAMES = ["c_attn_gemv(ln1+qkv)", "attention+attn_c_proj(fused,head-split)
                 "mlp_c_fc_gemv(resid-sum+ln2+gelu)", "mlp_c_proj_gemv(resid)", "head_gemv(2xln+mel_head)"]
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 OFFLINE_UTTS, OFFLINE_MICRO_BATCH = 64, 8     # BASELINE configs[2]; fixed per-GPU micro-batch
+OFFLINE_SEGMENTS = 2                          # a 10 s utterance at seg_len 6 s = a 6 s and a 4 s segment
 
 
 def kernel_bytes(dims, which, S, wb=4, kvb=4):
@@ -226,10 +227,19 @@ def offline_leg(wl, rank, world, dist, device):
         assert toks.shape[0] == OFFLINE_UTTS
         return OFFLINE_UTTS / dt
 
+    m.gpt.groups_stats = {"joint": 0, "separate": 0}
+    rate = run(OFFLINE_MICRO_BATCH, rank, world)
+    stats = dict(m.gpt.groups_stats)
+    variant = wl.eng.decode_variant()
+    # the micro-batch must have been decoded JOINTLY (its 6 s and 4 s classes in one step over 16 streams) on the multi-stream
+    # decode path, on every rank and at every world size: otherwise the N > 1 figure is not the N = 1 path times N
+    assert stats["separate"] == 0 and stats["joint"] > 0, f"offline leg: micro-batches were not decoded jointly ({stats})"
+    assert variant in (4, 5), f"offline leg: decode variant {variant}, expected the multi-stream step (4 rows path / 5 one-launch rows)"
     out = {"workload": f"{OFFLINE_UTTS} synthetic 10 s utterances (segments 6 s + 4 s: 141 + 94 tokens, fixed budget), top_k=1, tokens "
                        "only (BASELINE configs[2]); utterances sharded over the ranks, one all_gather of the token ids at the end",
            "micro_batch_utterances_per_gpu": OFFLINE_MICRO_BATCH, "n_gpus": world,
-           "offline_utts_per_s": run(OFFLINE_MICRO_BATCH, rank, world)}
+           "streams_per_decode_step": OFFLINE_SEGMENTS * OFFLINE_MICRO_BATCH, "joint_decodes": stats["joint"], "decode_variant": variant,
+           "offline_utts_per_s": rate}
     if world == 1:
         out["offline_utts_per_s_fully_batched_1gpu"] = run(OFFLINE_UTTS, 0, 1)
         out["note"] = ("a decode step streams the weights once whatever the batch: the fully batched figure is what one GPU can do, the "
@@ -304,7 +314,10 @@ def main():
 
     headline = args.streams == 1
     do_offline = headline and not args.no_offline and args.weights == "fp32"
-    slots_needed = max(8, OFFLINE_UTTS if (do_offline and world == 1) else OFFLINE_MICRO_BATCH)
+    # KV slots: a micro-batch of OFFLINE_MICRO_BATCH utterances is OFFLINE_SEGMENTS segment-streams per utterance decoded JOINTLY
+    # (layers/gpt.py generate_groups), so every rank needs that many slots whatever the world size -- the per-rank path at N > 1
+    # must be the one N = 1 is measured on; N = 1 also runs the fully batched figure (one class of OFFLINE_UTTS streams at a time)
+    slots_needed = max(16, OFFLINE_SEGMENTS * OFFLINE_MICRO_BATCH, OFFLINE_UTTS if (do_offline and world == 1) else 0)
     wl = Workload(device, rank, args.streams, args.weights, max_slots=slots_needed)
     for u in range(args.warmup):
         wl.utterance(u)

@@ -208,8 +208,22 @@ class GPT(nn.Module):
         kw = dict(generate_kwargs)
         greedy = kw.get("top_k", 0) == 1 or not kw.get("do_sample", True)
         total = sum(int(t.shape[0]) for _, t in groups)
+        stats = getattr(self, "groups_stats", None)        # {"joint": n, "separate": n}: bench.py / tests count the two paths
         if not greedy or len(groups) == 1 or total > self.max_slots or kw.get("num_beams", 1) != 1:
-            return [self.generate(c, t, **dict(kw)) for c, t in groups]
+            if stats is not None and len(groups) > 1:
+                stats["separate"] += 1
+            # one generate() per class; a sampling run gives every class its own random stream (the rows of one class keep the
+            # per-row numbering of the counter RNG): with one shared seed all classes would draw identical per-row sequences
+            outs = []
+            for gi, (c, t) in enumerate(groups):
+                kg = dict(kw)
+                if not greedy:
+                    kg["seed"] = int(kw.get("seed", 0)) + 7919 * gi
+                outs.append(self.generate(c, t, **kg))
+            self.last_latents = None      # (same contract as the joint path: callers of generate_groups want tokens)
+            return outs
+        if stats is not None:
+            stats["joint"] += 1
         group = kw.pop("group", 16)
         dev = groups[0][1].device
         max_new = kw.get("max_new_tokens") or self.max_gen_mel_tokens

@@ -55,7 +55,9 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
     """Tokens of a micro-batch of utterances.  Segment s of the utterances that HAVE a segment s of the same length forms
     one class (same prefix length: all full segments of the batch, and equal-length tails), prefilled in one batched call;
     tails of other lengths are classes of their own -- never padded, which would change the reference's result
-    (inference_utils.py:43-50).  The classes are then decoded together.
+    (inference_utils.py:43-50).  With greedy decoding (top_k = 1, the configuration BASELINE configs[2] names) the classes are
+    then decoded TOGETHER, as many per joint decode as the context has KV slots; a sampling run (top_k > 1) decodes one class
+    after another, each with its own random stream (layers/gpt.py generate_groups).
     Returns int32 [B, n_seg, max_len] padded with the stop token (also the rows of segments an utterance does not have)."""
     m = model
     stop = m.gpt.stop_audio_token

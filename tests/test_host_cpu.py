@@ -226,7 +226,9 @@ class _StubModel:
 
     class _Gpt:
         stop_audio_token, max_gen_mel_tokens = 1025, 12
+        max_slots = 16                                                        # KV slots: bounds the streams of one joint decode
         calls = []
+        group_calls = []                                                      # streams per class of every generate_groups call
 
         def generate(self, cond, codes, **kw):
             self.calls.append(tuple(codes.shape))
@@ -235,6 +237,8 @@ class _StubModel:
             return (base + torch.arange(n)[None, :]) % 1024
 
         def generate_groups(self, groups, **kw):                             # the real one decodes the groups together
+            self.group_calls.append([int(t.shape[0]) for _, t in groups])
+            assert sum(self.group_calls[-1]) <= self.max_slots or len(groups) == 1
             return [self.generate(c, t, **kw) for c, t in groups]
 
     content_extractor, content_dvae = _Extractor(), _Dvae()
@@ -242,6 +246,7 @@ class _StubModel:
     def __init__(self):
         self.gpt = self._Gpt()
         self.gpt.calls = []
+        self.gpt.group_calls = []
 
     def get_gpt_cond_latents(self, audio, sr):
         return audio[:, :64].reshape(1, 32, 2)
@@ -260,7 +265,7 @@ def _offline_worker(rank, world, port, q):
     srcs, ref = _offline_job()
     m = _StubModel()
     out = convert_offline(m, srcs, ref, seg_len=6.0, micro_batch=2, rank=rank, world=world)
-    q.put((rank, out.numpy(), len(m.gpt.calls)))
+    q.put((rank, out.numpy(), len(m.gpt.calls), m.gpt.group_calls))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -286,8 +291,29 @@ def test_convert_offline_world2_unequal_lengths():
     port = 31500 + (os.getpid() % 2000)
     ps = [ctx.Process(target=_offline_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
-    res = {r: (o, n) for r, o, n in (q.get(timeout=180) for _ in range(2))}
+    res = {r: (o, n, g) for r, o, n, g in (q.get(timeout=180) for _ in range(2))}
     [p.join(timeout=60) for p in ps]
     for r in range(2):
         assert np.array_equal(res[r][0], one.numpy())
     assert res[0][1] + res[1][1] <= len(m1.gpt.calls) + 3       # sharding does not multiply the generate calls
+    # every wave (micro-batch of 2 utterances) is ONE joint decode over all of its (segment, length) classes -- the per-rank path
+    # is the same at world size 1 and 2 (bench.py sized the KV slots so that N > 1 fell back to one decode per class)
+    for r in range(2):
+        n_mine = len(plan(lens, r, 2))
+        assert len(res[r][2]) == -(-n_mine // 2), res[r][2]
+        assert all(len(classes) >= 2 for classes in res[r][2][:1])          # the first wave holds utterances of >= 2 segments
+    assert len(m1.gpt.group_calls) == -(-len(srcs) // 2)
+
+
+def test_convert_batch_packs_classes_by_kv_slots():
+    """convert_batch packs as many (segment, length) classes into one joint decode as the context has KV slots; with too few
+    slots it degrades to more calls, never to a wrong result"""
+    from genvc_amd.parallel_offline import convert_offline
+    srcs, ref = _offline_job()
+    big, small = _StubModel(), _StubModel()
+    small.gpt.max_slots = 2
+    a = convert_offline(big, srcs, ref, seg_len=6.0, micro_batch=4)
+    b = convert_offline(small, srcs, ref, seg_len=6.0, micro_batch=4)
+    assert torch.equal(a, b)
+    assert len(big.gpt.group_calls) == 2 and len(small.gpt.group_calls) > 2
+    assert all(sum(c) <= 2 or len(c) == 1 for c in small.gpt.group_calls)
