@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "gpt_kernels.h"
 #include "persist_kernel.h"
+#include "persist_rows.h"
 #include "sampler.h"
 
 namespace gvc {
@@ -243,6 +244,18 @@ struct gvc_gpt {
     int p_ring_slots = 0, p_ascr = 0, p_hvec = 0;
     size_t p_lds = 0;
     int last_variant = 0;             // decode variant of the last gvc_gpt_generate call (gvc_gpt_decode_variant)
+    // one-launch block stack for 2..16 rows (persist_rows.h): batched decode steps, cached chunk prefills
+    int persist_rows = 1;             // GVC_PERSIST_ROWS=0: those calls keep the launch-per-phase rows path
+    int persist_rows_min = 2;         // GVC_PERSIST_ROWS_MIN: smallest row count served
+    long long r_launches = 0;         // one-launch rows steps issued (gvc_gpt_rows_step_launches; graph replays count once per capture)
+    int r_ready = 0;                  // 0 not prepared yet, 1 ready, -1 unavailable on this device / for these dims
+    RowsLayer* r_layers = nullptr;
+    float* r_wpack = nullptr;         // packed weights [layer][256][192 KiB]
+    float* r_bufs = nullptr;          // hand-off buffers, two parities
+    unsigned long long* r_dbg = nullptr;   // GVC_PERSIST_STAMPS
+    size_t r_lds = 0;
+    int rows_keys_hint = 0;           // cached positions the longest stream of the running call reaches (set by the entry points)
+    int r_split1 = 128, r_split2 = 288;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
 };
 
 static int gemv_init();
@@ -348,6 +361,9 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     *c->seam_err_host = 0;
     GVC_CHECK_HIP(hipHostGetDevicePointer((void**)&c->seam_err_dev, c->seam_err_host, 0));
     if (getenv("GVC_PERSIST")) c->persist = atoi(getenv("GVC_PERSIST"));
+    if (getenv("GVC_PERSIST_ROWS")) c->persist_rows = atoi(getenv("GVC_PERSIST_ROWS"));
+    if (getenv("GVC_PERSIST_ROWS_MIN")) c->persist_rows_min = std::max(2, atoi(getenv("GVC_PERSIST_ROWS_MIN")));
+    if (getenv("GVC_ROWS_PERSIST_SPLIT")) sscanf(getenv("GVC_ROWS_PERSIST_SPLIT"), "%d,%d", &c->r_split1, &c->r_split2);
     if (getenv("GVC_DEBUG_STAMPS")) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->dbg, 4096 * 8 * sizeof(unsigned long long)));
         GVC_CHECK_HIP(hipMemset(c->dbg, 0, 4096 * 8 * sizeof(unsigned long long)));
@@ -362,7 +378,8 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->xalt) hipFree(c->xalt);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
-    for (void* p : {(void*)c->p_layers, (void*)c->p_gran, (void*)c->p_epoch, (void*)c->p_dbg})
+    for (void* p : {(void*)c->p_layers, (void*)c->p_gran, (void*)c->p_epoch, (void*)c->p_dbg, (void*)c->r_layers, (void*)c->r_wpack,
+                    (void*)c->r_bufs, (void*)c->r_dbg})
         if (p) hipFree(p);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->slot_logits, (void*)c->slot_latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
@@ -690,6 +707,89 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     return GVC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// one-launch block stack for 2..16 rows (persist_rows.h)
+// ---------------------------------------------------------------------------------------------
+static bool rows_persist_ok(const gvc_gpt* c, int rows, const int32_t* base_len) {
+    return c->persist && c->persist_rows && c->r_ready >= 0 && base_len && rows >= c->persist_rows_min && rows <= kRMaxRows &&
+           c->dm.d_model == kRD && c->hd == kRHD && c->dm.n_head == 4 && !c->bf16 && !c->kv_bf16 && c->dm.n_layer % 2 == 0 &&
+           c->n_cu >= kPG;
+}
+
+// key chunks per (row, head) for a call whose longest context reaches `keys` cached positions
+static int rows_persist_chunks(const gvc_gpt* c, int rows, int keys) {
+    (void)keys;                              // (the kernel picks the split from the contexts it finds; this is the bound)
+    int nch = kRMaxChunks;
+    const int R = rows <= 8 ? 8 : 16;
+    while (nch > 1 && R * c->dm.n_head * nch > kPG) nch >>= 1;
+    return nch;
+}
+
+static void rows_persist_release(gvc_gpt* c) {
+    for (void** p : {(void**)&c->r_layers, (void**)&c->r_wpack, (void**)&c->r_bufs, (void**)&c->r_dbg})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    (void)hipGetLastError();
+    c->r_ready = -1;
+}
+
+// packed weight copy, per-layer table, hand-off buffers; called outside stream capture (synchronous).  Anything the device
+// refuses (memory, LDS opt-in, residency) switches the path off for this context instead of failing the call.
+static int rows_persist_prepare(gvc_gpt* c) {
+    if (c->r_ready != 0) return GVC_OK;
+    const int L = c->dm.n_layer;
+    c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
+               kCtlWords * sizeof(unsigned);
+    int per_cu = 0;
+    if (hipFuncSetAttribute((const void*)k_rows_persist<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_rows_persist<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rows_persist<16>, kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rows_persist<8>, kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
+        hipMalloc((void**)&c->r_wpack, (size_t)L * kPG * kRWgLayerBytes) != hipSuccess ||
+        hipMalloc((void**)&c->r_bufs, rows_buf_bytes()) != hipSuccess ||
+        hipMalloc((void**)&c->r_layers, L * sizeof(RowsLayer)) != hipSuccess) {
+        rows_persist_release(c);
+        return GVC_OK;
+    }
+    std::vector<RowsLayer> t(L);
+    for (int l = 0; l < L; ++l) {
+        const GptLayer& ly = c->layers[l];
+        RowsLayer& p = t[l];
+        p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_b = ly.qkv_b; p.proj_b = ly.proj_b; p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b;
+        p.fc_b = ly.fc_b; p.p2_b = ly.p2_b; p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
+        hipLaunchKernelGGL(k_pack_rows_weights, dim3(2048), dim3(256), 0, 0,
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * kRWgLayerBytes),
+                           (const float*)ly.qkv_w, (const float*)ly.proj_w, (const float*)ly.fc_w, (const float*)ly.p2_w);
+    }
+    if (hipGetLastError() != hipSuccess || hipMemcpy(c->r_layers, t.data(), L * sizeof(RowsLayer), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->r_bufs, 0xff, rows_buf_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        rows_persist_release(c);
+        return GVC_OK;
+    }
+    if (getenv("GVC_PERSIST_STAMPS")) {
+        GVC_CHECK_HIP(hipMalloc((void**)&c->r_dbg, (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long)));
+        GVC_CHECK_HIP(hipMemset(c->r_dbg, 0, (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long)));
+    }
+    c->r_ready = 1;
+    return GVC_OK;
+}
+
+static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T, const int32_t* base_len, int nch, hipStream_t s) {
+    RowsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.layers = c->r_layers; A.wpack = reinterpret_cast<const char*>(c->r_wpack); A.n_layer = c->dm.n_layer; A.n_head = c->dm.n_head;
+    A.max_seq = c->dm.max_seq; A.rows = rows; A.T = T; A.slots = slots; A.base_len = base_len; A.x = c->x; A.bufs = c->r_bufs;
+    A.err = c->seam_err_dev; A.ring_slots = 8; A.nchunks = nch; A.dbg = c->r_dbg;
+    static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
+    A.poll_all = poll_all;
+    A.split1 = c->r_split1; A.split2 = c->r_split2;
+    if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8>), dim3(kPG), dim3(kPThreads), c->r_lds, s, A);
+    else hipLaunchKernelGGL((k_rows_persist<16>), dim3(kPG), dim3(kPThreads), c->r_lds, s, A);
+    GVC_LAUNCH_CHECK();
+    c->r_launches += 1;
+    return GVC_OK;
+}
+
 static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const int32_t* tok_in, float* logits_out,
                         float* latent_out, int32_t* step_ctr, hipStream_t s, bool fused = false) {
     const int d = c->dm.d_model;
@@ -758,6 +858,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
 // once for up to 128 streams) instead of the 8-stream GEMV groups.  Same arithmetic as a prefill of one row per stream
 // appended at each slot's cached length.
 static bool rows_decode_ok(const gvc_gpt* c, int B) {
+    if (c->r_ready >= 0 && rows_persist_ok(c, B, c->st.seq_len)) return true;       // served by the one-launch rows step (from 2 streams)
     return c->rows_decode_min > 0 && B >= c->rows_decode_min && B <= 128 && c->skinny_prefill && c->wfm &&
            c->dm.d_model % 256 == 0 && (long long)4 * B * c->dm.d_model <= c->work_cap / 2 && B <= c->dm.max_rows;
 }
@@ -803,6 +904,8 @@ extern "C" int gvc_gpt_decode_step(gvc_gpt* c, const int32_t* slots, int32_t B, 
     hipStream_t s = (hipStream_t)sv;
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     if (persist_ok(c, B)) return launch_persist(c, slots, tok_in, logits_out, latent_out, nullptr, s);
+    if (rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    c->rows_keys_hint = c->dm.max_seq;            // (no bound from the caller: the key split for the longest possible context)
     if (rows_decode_ok(c, B)) return decode_rows(c, slots, B, tok_in, logits_out, latent_out, nullptr, s);
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
@@ -842,6 +945,9 @@ extern "C" int gvc_gpt_prefix_embeddings(gvc_gpt* c, const float* cond, int32_t 
 static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len, int key_chunks) {
     const int d = c->dm.d_model, rows = B * T;
     int rc;
+    // 2..16 rows that continue cached sequences (a batched decode step, the uncached rows of a streaming chunk): ONE launch
+    if (c->r_ready == 1 && rows_persist_ok(c, rows, base_len))
+        return launch_rows_persist(c, slots, rows, T, base_len, rows_persist_chunks(c, rows, c->rows_keys_hint), s);
     const bool skinny = c->skinny_prefill && c->wfm && rows <= 128 && d % 256 == 0 && (long long)4 * rows * d <= c->work_cap / 2;
     const int SKP = 4;
     float* part_proj = c->work;                                    // [SKP][rows][d]
@@ -1003,6 +1109,8 @@ extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t 
                        (const int32_t*)nullptr, 0, start_tok, start_tok, n_cached);
     GVC_LAUNCH_CHECK();
     const int Tn = T - n_cached;
+    if (n_cached > 0 && rows_persist_ok(c, B * Tn, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    c->rows_keys_hint = T;
     if (n_cached > 0) {
         // the rows continue the cached prefix: K/V go to positions n_cached.., attention sees [0, n_cached + t]
         hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, n_cached, 0);
@@ -1113,9 +1221,12 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
     const int key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
                                ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
-    const int key = B * 2 + (fused ? 1 : 0) + 4096 * key_chunks;          // (the one-launch step is a pure function of B)
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
-    c->last_variant = persist_ok(c, B) ? 3 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1));
+    if (!persist_ok(c, B) && rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    const bool rows1 = !persist_ok(c, B) && c->r_ready == 1 && rows_persist_ok(c, B, c->st.seq_len);      // one-launch rows step
+    c->rows_keys_hint = key_bound;
+    const int key = B * 2 + (fused ? 1 : 0) + 4096 * (rows1 ? 8 + rows_persist_chunks(c, B, key_bound) : key_chunks);   // (the one-launch steps are pure functions of B [and the key split])
+    c->last_variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1)));
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraphExec_t ge;
@@ -1194,9 +1305,16 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
 }
 
 extern "C" int gvc_gpt_decode_variant(gvc_gpt* c) { return c ? c->last_variant : 0; }
+extern "C" long long gvc_gpt_rows_step_launches(gvc_gpt* c) { return c ? c->r_launches : 0; }
 
 // debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {
+    if (c && c->r_dbg && max_launches == -2) {    // stamps of the last one-launch rows step: workgroup 0, [(layer * 5 + phase) * 4 + k]
+        (void)hipDeviceSynchronize();
+        const int n = 20 * (c->dm.n_layer + 2) + 4 * 5 * kPG;
+        (void)hipMemcpy(host_out, c->r_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        return n;
+    }
     if (c && c->p_dbg && max_launches < 0) {     // stamps of the last one-launch decode step (layout: persist_kernel.h)
         (void)hipDeviceSynchronize();
         const int n = 20 * (c->dm.n_layer + 2) + 2 * 5 * kPG;

@@ -1,0 +1,800 @@
+// One-launch block stack for 2..16 ROWS (reference: one iteration of layers/stream_generator.py:809-881 over B streams -- each
+// row is one stream's new position, gpt_inference.py:92-112 -- or the <= 16 uncached rows of a streaming chunk's prefill,
+// gpt_inference.py:81-91; block arithmetic: SURVEY.md Appendix A).
+//
+// Same engine as the one-stream step (persist_kernel.h): 256 resident workgroups, a loader wave per workgroup that streams the
+// workgroup's weights through an LDS ring with LDS-DMA, eight consumer waves that gather a phase input, compute and publish.
+// What is different with R rows:
+//   * arithmetic on the matrix cores: v_mfma_f32_4x4x1_16b_f32 (exact fp32) multiplies FOUR weight rows by all R activation
+//     rows -- its 16 blocks are (R / 4 row groups) x (16 / (R / 4) k positions) -- so the row partition of the one-stream step
+//     (12 / 4 / 16 / 4 weight rows per workgroup and phase, whole K, one output plane) carries over with no padding waste;
+//   * weights come from a packed copy, contiguous per (layer, workgroup): each 4-row group "k-quad-major" ([k / 4][row][4]), so a
+//     ring slot read with ds_read_b128 is the A operand of four consecutive MFMAs and needs no bank padding;
+//   * activations travel in the B-operand order of the NEXT phase ("frag" layout: 1 KiB = one float4 per lane of one MFMA step),
+//     so a consumer wave loads its K-slice straight into registers: no activation staging in LDS, each workgroup reads a
+//     hand-off buffer exactly once;
+//   * hand-offs carry NO tags or flags: every element of a buffer is written by exactly one lane per layer; the buffers exist in
+//     two parities (layer & 1) and a producer poisons (0xffffffff) its own elements of the OTHER parity right after publishing --
+//     they were last read a layer ago -- and drains that store before its next publish.  A consumer re-reads a 16-byte piece
+//     until none of its dwords is the poison pattern (scripts/ubench/seam_rows.hip: 2.4-3.9 us per 16-128 KB all-to-all, no
+//     wrong value in 4e8 checked).  16-byte write-through (sc1) stores, 16-byte sc1 loads.  Why a reader can never take a stale
+//     element for a fresh one: every consumer wave gathers in every phase and the first use of a gathered value waits for ALL of
+//     the wave's outstanding memory operations (vmcnt(0)), stores included -- so a wave's poison stores have landed before its
+//     workgroup publishes the next phase, and a reader polls an element for layer l + 2 only after it has (transitively) seen
+//     publishes of every workgroup that are younger than that workgroup's poison of layer l + 1.
+// Per layer: A [LN1, c_attn -> q|k|v rows, k/v appended to the cache] -> B [attention of one (row, head, key chunk) per
+// workgroup] -> C [merge of the chunk partials, attn c_proj, residual] -> D [LN2, c_fc, gelu_new] -> E [mlp c_proj, residual].
+// The head (double LayerNorm + mel_head) stays with the caller's launches.  d_model 1024, head_dim 256, an even layer count.
+#pragma once
+#include <type_traits>
+
+#include "persist_kernel.h"
+
+namespace gvc {
+
+constexpr int kRD = 1024, kRHD = 256;
+constexpr unsigned kRPoison = 0xffffffffu;
+constexpr int kRWgLayerBytes = 192 * 1024;        // packed weights per workgroup and layer: 12 ring fills
+constexpr int kRMaxChunks = 4;                    // key chunks per (row, head)
+constexpr int kRMaxRows = 16;
+// hand-off buffers (floats inside one parity), sized for 16 rows
+constexpr int kRoffQKV = 0;
+constexpr int kRoffOP = kRoffQKV + kRMaxRows * 3 * kRD;                       // [chunk][frag of R x D]
+constexpr int kRoffML = kRoffOP + kRMaxChunks * kRMaxRows * kRD;              // [chunk][row][head] float4 {m, l, 0, 0}
+constexpr int kRoffX0 = kRoffML + kRMaxChunks * kRMaxRows * 4 * 4;
+constexpr int kRoffHH = kRoffX0 + kRMaxRows * kRD;
+constexpr int kRoffX1 = kRoffHH + kRMaxRows * 4 * kRD;
+constexpr int kRParFloats = kRoffX1 + kRMaxRows * kRD;
+__host__ __device__ static inline size_t rows_buf_bytes() { return (size_t)2 * kRParFloats * sizeof(float); }
+
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+
+struct RowsLayer {
+    const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc_b, *p2_b;
+    float *kcache, *vcache;         // this layer's [slot][head][max_seq][hd]
+};
+
+struct RowsArgs {
+    const RowsLayer* layers;
+    const char* wpack;              // [layer][256 workgroups][192 KiB]
+    int n_layer, n_head, max_seq;
+    int rows, T;                    // active rows; rows [b T, (b + 1) T) continue stream b at base_len[slot b] + 0 .. T - 1
+    const int32_t* slots;
+    const int32_t* base_len;        // per slot; null: 0
+    float* x;                       // [rows][1024] row-major: block-stack input, overwritten with its output
+    float* bufs;                    // [2][kRParFloats]
+    int* err;
+    int ring_slots, nchunks;        // nchunks: upper bound of the key split (the kernel picks 1 / 2 / 4 from the longest context it finds)
+    int split1, split2;             // cached positions from which the keys of a (row, head) take 2 / 4 workgroups
+    int poll_all;                   // gathers of up to this many 16-byte pieces per lane re-request everything in every poll pass
+    unsigned long long* dbg;
+};
+
+// packed weights: [layer][wg]{ A: 3 groups | C: 1 | D: 4 | E: 1 }, group = 4 rows x K as [K / 4][4 rows][4]
+__global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* proj, const float* fc, const float* p2) {
+    const size_t n4 = (size_t)kPG * kRWgLayerBytes / 16;                 // float4 per layer
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int wg = (int)(i / (kRWgLayerBytes / 16));
+        int r = (int)(i - (size_t)wg * (kRWgLayerBytes / 16));         // float4 inside the workgroup's block
+        const float* src;
+        int K, row0;
+        // a 4-row group over K = 1024 is 1024 float4 (one ring fill), over K = 4096 it is 4096 float4 (four fills)
+        if (r < 3 * 1024) { src = qkv; K = kRD; row0 = wg * 12 + (r >> 10) * 4; r &= 1023; }
+        else if (r < 4 * 1024) { src = proj; K = kRD; row0 = wg * 4; r -= 3 * 1024; }
+        else if (r < 8 * 1024) { r -= 4 * 1024; src = fc; K = kRD; row0 = wg * 16 + (r >> 10) * 4; r &= 1023; }
+        else { r -= 8 * 1024; src = p2; K = 4 * kRD; row0 = wg * 4; }
+        const int t = r & 3, q = r >> 2;
+        reinterpret_cast<float4*>(dst)[i] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + t) * K + q * 4);
+    }
+}
+
+__device__ __forceinline__ bool rclean(pu32x4 v) { return v.x != kRPoison && v.y != kRPoison && v.z != kRPoison && v.w != kRPoison; }
+__device__ __forceinline__ float4 as_f4(pu32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ pu32x4 as_u4(float4 v) {
+    pu32x4 r = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    return r;
+}
+
+// 16-byte write-through store of a hand-off element and the poison of the same element in the other parity
+__device__ __forceinline__ void rpublish(__amdgpu_buffer_rsrc_t rs, int off_cur, int off_other, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(as_u4(v), rs, off_cur, 0, 16);
+    const pu32x4 p = {kRPoison, kRPoison, kRPoison, kRPoison};
+    __builtin_amdgcn_raw_buffer_store_b128(p, rs, off_other, 0, 16);
+}
+
+// NL 16-byte pieces per lane at byte offsets off + i * stride: polls piece 0, then requests the rest and re-requests the pieces
+// that still hold poison
+template <int NL>
+__device__ __forceinline__ void rgather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int off, int stride, pu32x4 (&v)[NL], int code, bool poll_all = false) {
+    if (NL > 1 && poll_all) {        // every poll pass requests everything: one round trip less once the data is there
+        unsigned spins = 0;
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) ok = ok && rclean(v[i]);
+            if (__all(ok)) break;
+            if (spin_fail(c, spins, code, 1)) break;
+        }
+        return;
+    }
+    // (no early exits: a path that leaves v[] undefined makes every gathered array live across the whole layer loop and
+    //  the kernel spills ~400 registers; a dead workgroup falls through the polls within 64 spins each, spin_fail)
+    unsigned spins = 0;
+    while (true) {
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        if (__all(rclean(v[0]))) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+    if (NL == 1) return;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16);
+    while (true) {
+        bool again = false;
+#pragma unroll
+        for (int i = 1; i < NL; ++i) {
+            if (__any(!rclean(v[i]))) { v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16); again = true; }
+        }
+        if (!again) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+}
+
+// sum over the lanes that share (row group, row-in-group) and differ in the k position: lane = (g KK + kk) 4 + t
+template <int R>
+__device__ __forceinline__ float kk_sum(float v) {
+    v += dpp_mov<0x124>(v);          // row_ror:4
+    v += dpp_mov<0x128>(v);          // row_ror:8
+    if (R <= 8) v += __shfl_xor(v, 16);
+    if (R <= 4) v += __shfl_xor(v, 32);
+    return v;
+}
+
+// ---- loader wave -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ring) {
+    const unsigned rmask = A.ring_slots - 1;
+    unsigned fseq = 0;
+    const char* base = A.wpack + (size_t)c.wg * kRWgLayerBytes + c.lane * 16;
+#pragma unroll 1
+    for (int l = 0; l < A.n_layer; ++l) {
+        const char* lsrc = base + (size_t)l * kPG * kRWgLayerBytes;
+#pragma unroll 1
+        for (int f = 0; f < kRWgLayerBytes / kPSlot; ++f) {
+            unsigned spins = 0;
+            bool drained = false;
+            while (!c.dead) {
+                unsigned m = lds_ld(c.ctl + kCtlDone);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) m = min(m, lds_ld(c.ctl + kCtlDone + w));
+                if (fseq < m + (unsigned)A.ring_slots) break;
+                if (!drained) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_st(c.ctl + kCtlFilled, fseq);
+                    drained = true;
+                }
+                if (spin_fail(c, spins, 902, 1)) break;
+            }
+            if (c.dead) return;
+            char* dst = ring + (size_t)__builtin_amdgcn_readfirstlane(fseq & rmask) * kPSlot;
+            const char* src = lsrc + (size_t)f * kPSlot;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            lds_st(c.ctl + kCtlFilled, fseq);
+            ++fseq;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_st(c.ctl + kCtlFilled, fseq);
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------
+template <int R>       // padded row count: 8 or 16
+__global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
+    constexpr int D = kRD, HD = kRHD;
+    constexpr int G = R / 4, KK = 16 / G;            // row groups, k positions (quads) per MFMA step
+    constexpr int NSX = D / 4 / KK / kPCW;           // MFMA steps (of 4 instructions) per wave over K = D      (16 rows: 8, 8 rows: 4)
+    constexpr int NSH = 4 * NSX;                     // ... over K = 4 D
+    constexpr int STEPB = KK * 64;                   // bytes of a 4-row weight group per step
+    constexpr int LMASK = KK * 4 - 1;                // lanes that read distinct A operands
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    float* red = reinterpret_cast<float*>(ring + (size_t)A.ring_slots * kPSlot);      // [kPCW][4 groups][R] float4
+    float* stat = red + kPCW * 4 * kRMaxRows * 4;    // [2][kPCW][16]
+    float* resid = stat + 2 * kPCW * 16;             // [R] float4: the residual of this workgroup's four output columns
+    float* gbs = resid + kRMaxRows * 4;              // [kPCW][32 gain quads | 32 bias quads] of the LayerNorm a phase applies
+    float* ascr = gbs + kPCW * 64 * 4;               // attention: q[256] | m_s[8] | l_s[8] | o_s[8][256]
+    unsigned* ctl = reinterpret_cast<unsigned*>(ascr + 256 + 16 + kPCW * 256);
+    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0u;
+    __syncthreads();
+
+    PCtx c;
+    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.wg = blockIdx.x;
+    c.ctl = ctl; c.err = A.err; c.bar_target = 0; c.filled_seen = 0; c.dead = false;
+    if (c.wave == kPCW) {
+        rows_loader(A, c, ring);
+        return;
+    }
+    int& lane = c.lane;
+    const int wave = c.wave, wg = c.wg;
+#define GVC_PHASE_BEGIN() asm volatile("" : "+v"(c.lane), "+s"(Lp))
+    const unsigned rmask = A.ring_slots - 1;
+    const int H = A.n_head;
+    // key chunks per (row, head): from the longest context among the rows (per-slot lengths live on the device: every workgroup
+    // reads the same few words and decides alike)
+    int nch;
+    {
+        int keys = 0;
+        if (c.lane < A.rows) {
+            const int b0 = c.lane / A.T;
+            keys = (A.base_len ? A.base_len[A.slots[b0]] : 0) + (c.lane - b0 * A.T) + 1;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) keys = max(keys, __shfl_xor(keys, o));
+        keys = __builtin_amdgcn_readfirstlane(keys);
+        nch = keys > A.split2 ? 4 : (keys > A.split1 ? 2 : 1);
+        if (nch > A.nchunks) nch = A.nchunks;
+    }
+    const __amdgpu_buffer_rsrc_t brs = make_rsrc(A.bufs, (unsigned)rows_buf_bytes());
+    const float scale = 1.0f / sqrtf((float)HD);
+    // stamps (GVC_PERSIST_STAMPS): workgroup 0, every layer: [(l * 5 + p) * 4 + k], k = 0 input gathered, 1 output published, 2 extra;
+    // every workgroup at layer 2: [20 (L + 2) + (wg * 5 + p) * 4 + k]
+    const bool stamp0 = A.dbg && wave == 0 && c.lane == 0;
+    const int sbase2 = 20 * (A.n_layer + 2);
+    auto stamp_at = [&](int l, int p, int k) {
+        if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 4 + k] = wall_clock64();
+        if (stamp0 && l == 2) A.dbg[sbase2 + (wg * 5 + p) * 4 + k] = wall_clock64();
+    };
+    unsigned fs = 0;
+    auto phase_done = [&]() { if (lane == 0) lds_st(ctl + kCtlDone + wave, fs); };
+
+    for (int l = 0; l < A.n_layer; ++l) {
+        const RowsLayer* Lp = A.layers + l;
+        const int pc = (l & 1) * kRParFloats * 4, po = ((l & 1) ^ 1) * kRParFloats * 4;      // byte offsets of the two parities
+        // lane roles in the frag layout
+        // =================== A: LN1 -> c_attn rows -> q | k | v ===================
+        {
+            GVC_PHASE_BEGIN();
+            const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
+            const int s0 = wave * NSX;
+            float4 xv[NSX];
+            const float4 bpre = *reinterpret_cast<const float4*>(Lp->qkv_b + wg * 12 + (wave < 3 ? wave : 0) * 4);   // (requested ahead of the seam)
+            // LayerNorm gains / biases of the wave's 32 k-quads -> LDS (read back one step at a time next to the MFMAs)
+            *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) =
+                *reinterpret_cast<const float4*>((lane < 32 ? Lp->ln1_w : Lp->ln1_b) + (s0 * KK + (lane & 31)) * 4);
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    const int q = (s0 + i) * KK + kk;
+                    xv[i] = n < A.rows ? *reinterpret_cast<const float4*>(A.x + (size_t)n * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
+                pu32x4 raw[NSX];
+                rgather<NSX>(c, brs, po + kRoffX1 * 4 + s0 * 1024 + lane * 16, 1024, raw, 100 + l, NSX <= A.poll_all);
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) xv[i] = as_f4(raw[i]);
+            }
+            stamp_at(l, 0, 0);
+            // residual of this workgroup's output columns [4 wg, 4 wg + 4) of phase C: k-quad wg of x
+            {
+                const int sq = wg / KK;
+                if (sq >= s0 && sq < s0 + NSX && kk == wg % KK) {
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i)
+                        if (i == sq - s0) *reinterpret_cast<float4*>(resid + n * 4) = xv[i];
+                }
+            }
+            // LayerNorm: per-wave (mean, M2) of the wave's K-slice, merged over the eight waves (Chan et al.)
+            float mean_, rstd_;
+            {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+                const float mw = kk_sum<R>(s) * (1.0f / (float)(NSX * KK * 4));
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    const float a0 = xv[i].x - mw, a1 = xv[i].y - mw, a2 = xv[i].z - mw, a3 = xv[i].w - mw;
+                    m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+                m2 = kk_sum<R>(m2);
+                if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
+                cbar(c);
+                float mean = 0.f;
+#pragma unroll
+                for (int w = 0; w < kPCW; ++w) mean += stat[w * 16 + n];
+                mean *= 1.0f / (float)kPCW;
+                float M2 = 0.f, dv = 0.f;
+#pragma unroll
+                for (int w = 0; w < kPCW; ++w) {
+                    const float dm = stat[w * 16 + n] - mean;
+                    M2 += stat[kPCW * 16 + w * 16 + n];
+                    dv += dm * dm;
+                }
+                const float var = (M2 + dv * (float)(NSX * KK * 4)) * (1.0f / (float)D);
+                rstd_ = 1.0f / sqrtf(var + 1e-5f);
+                mean_ = mean;
+            }
+            pf32x4 acc[3];
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+            wait_fill(c, fs + 2);
+            {
+                // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
+                // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
+                const char* wbase = ring + (s0 * STEPB + (lane & LMASK) * 16);
+                const float* gb = gbs + (wave * 64 + kk) * 4;
+                float4 wc[3], wn[3], gc, bc, gn, bn;
+#pragma unroll
+                for (int rg = 0; rg < 3; ++rg) wc[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+                gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    if (i + 1 < NSX) {
+#pragma unroll
+                        for (int rg = 0; rg < 3; ++rg) wn[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (i + 1) * STEPB);
+                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
+                    }
+                    const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
+                    const float x2 = (xv[i].z - mean_) * rstd_ * gc.z + bc.z, x3 = (xv[i].w - mean_) * rstd_ * gc.w + bc.w;
+#pragma unroll
+                    for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].x, x0, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].y, x1, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].z, x2, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].w, x3, acc[rg], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rg = 0; rg < 3; ++rg) wc[rg] = wn[rg];
+                    gc = gn; bc = bn;
+                }
+            }
+            stamp_at(l, 0, 2);
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg) {
+                const float4 r = make_float4(kk_sum<R>(acc[rg][0]), kk_sum<R>(acc[rg][1]), kk_sum<R>(acc[rg][2]), kk_sum<R>(acc[rg][3]));
+                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + rg) * kRMaxRows + n) * 4) = r;
+            }
+            fs += 3;
+            phase_done();
+            cbar(c);
+            stamp_at(l, 0, 3);
+            if (wave < 3 && lane < R) {                       // wave rg finishes row group rg for row `lane`
+                const int rg = wave, rn = lane;
+                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + rg) * kRMaxRows + rn) * 4);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) {
+                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + rg) * kRMaxRows + rn) * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                const int col = wg * 12 + rg * 4;
+                const float4 bi = bpre;
+                s.x += bi.x; s.y += bi.y; s.z += bi.z; s.w += bi.w;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's poison of the previous layer has landed
+                const int eo = (kRoffQKV + rn * 3 * D + col) * 4;
+                rpublish(brs, pc + eo, po + eo, s);
+                if (col >= D && rn < A.rows) {                // append k / v of this row to its stream's cache (read by later launches)
+                    const int which = col / D, ci = col - which * D, h = ci / HD, j = ci - h * HD;
+                    const int bstream = rn / A.T, t = rn - bstream * A.T, slot = A.slots[bstream];
+                    const int pos = (A.base_len ? A.base_len[slot] : 0) + t;
+                    if (pos < A.max_seq) {
+                        float* cache = which == 1 ? Lp->kcache : Lp->vcache;
+                        *reinterpret_cast<float4*>(cache + (((size_t)slot * H + h) * A.max_seq + pos) * HD + j) = s;
+                    } else *A.err = 950;                      // KV cache full: GVC_ERR_STATE on the host's next call
+                }
+            }
+            stamp_at(l, 0, 1);
+        }
+        // =================== B: attention of one (row, head, key chunk) per workgroup ===================
+        if (wg < R * H * nch) {
+            GVC_PHASE_BEGIN();
+            const int ch = wg % nch, h = (wg / nch) % H, n = wg / (nch * H);
+            const bool active = n < A.rows;
+            const int bstream = active ? n / A.T : 0, t = active ? n - bstream * A.T : 0, r0 = bstream * A.T;
+            const int slot = A.slots[bstream];
+            const int base = A.base_len ? A.base_len[slot] : 0;
+            const int k0 = active ? (int)(((long long)base * ch) / nch) : 0, k1 = active ? (int)(((long long)base * (ch + 1)) / nch) : 0;
+            const bool last = active && ch == nch - 1;           // the new rows [r0, n] of this very step belong to the last chunk
+            const unsigned head_bytes = (unsigned)A.max_seq * HD * 4u;
+            const __amdgpu_buffer_rsrc_t krs = make_rsrc(Lp->kcache + ((size_t)slot * H + h) * A.max_seq * HD, head_bytes);
+            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(Lp->vcache + ((size_t)slot * H + h) * A.max_seq * HD, head_bytes);
+            constexpr int U = 8;                                 // keys per wave and pass: 64 keys of the chunk per pass
+            float4 kr[U], vr[U];
+            auto load_pass = [&](int kb) {                       // keys kb + wave + 8 u of the cache (written by earlier launches)
+                const int voff = ((kb + wave) * HD + lane * 4) * 4;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    pu32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
+                    if (kb + wave + u * kPCW < k1) {
+                        kq = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * HD * 4, 0);
+                        vq = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * HD * 4, 0);
+                    }
+                    kr[u] = as_f4(kq); vr[u] = as_f4(vq);
+                }
+            };
+            load_pass(k0);                                       // requested ahead of the seam
+            // q of (row, head): 256 floats, one 16-byte load per lane of wave 0
+            if (wave == 0 && active) {
+                pu32x4 qv[1];
+                rgather<1>(c, brs, pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16, 0, qv, 200 + l);
+                *reinterpret_cast<float4*>(ascr + lane * 4) = as_f4(qv[0]);
+            }
+            // new rows r0 + j <= n of this very step: k and v from the hand-off buffer; row j belongs to wave (j + 1) % 8, so a decode
+            // step's single new key is gathered beside q, not behind it
+            float4 kn[2], vn[2];
+            bool has_new[2] = {false, false};
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = ((wave + kPCW - 1) & (kPCW - 1)) + jj * kPCW;
+                kn[jj] = vn[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (last && j <= t) {
+                    has_new[jj] = true;
+                    pu32x4 kv[2];
+                    rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l);
+                    kn[jj] = as_f4(kv[0]); vn[jj] = as_f4(kv[1]);
+                }
+            }
+            cbar(c);
+            stamp_at(l, 1, 0);
+            const float4 q4 = *reinterpret_cast<const float4*>(ascr + lane * 4);
+            float m = -INFINITY, lsum = 0.f;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            // online softmax over a batch of NB scores (-inf: no key): one rescale per batch
+            auto fold = [&](auto& sc, auto& vv, auto nb) {
+                constexpr int NB = decltype(nb)::value;
+                float mn = m;
+#pragma unroll
+                for (int u = 0; u < NB; ++u) mn = fmaxf(mn, sc[u]);
+                if (mn > -INFINITY) {                            // (wave-uniform)
+                    const float alpha = __expf(m - mn);
+                    lsum *= alpha; o.x *= alpha; o.y *= alpha; o.z *= alpha; o.w *= alpha;
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const float p = __expf(sc[u] - mn);
+                        lsum += p;
+                        o.x = fmaf(p, vv[u].x, o.x); o.y = fmaf(p, vv[u].y, o.y);
+                        o.z = fmaf(p, vv[u].z, o.z); o.w = fmaf(p, vv[u].w, o.w);
+                    }
+                    m = mn;
+                }
+            };
+            for (int kb = k0; kb < k1; kb += U * kPCW) {
+                if (kb > k0) load_pass(kb);
+                float sc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) sc[u] = dot4(q4, kr[u]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) sc[u] = kb + wave + u * kPCW < k1 ? wave_sum(sc[u]) * scale : -INFINITY;
+                fold(sc, vr, std::integral_constant<int, U>());
+            }
+            {
+                float sc[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) sc[jj] = has_new[jj] ? wave_sum(dot4(q4, kn[jj])) * scale : -INFINITY;
+                fold(sc, vn, std::integral_constant<int, 2>());
+            }
+            float* m_s = ascr + 256;
+            float* l_s = m_s + kPCW;
+            float* o_s = l_s + kPCW;
+            if (lane == 0) { m_s[wave] = m; l_s[wave] = lsum; }
+            *reinterpret_cast<float4*>(o_s + wave * 256 + lane * 4) = o;
+            cbar(c);
+            if (wave == 0) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < kPCW; ++i) M = fmaxf(M, m_s[i]);
+                float Lt = 0.f;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (M > -INFINITY) {
+#pragma unroll
+                    for (int i = 0; i < kPCW; ++i) {
+                        const float wgt = __expf(m_s[i] - M);              // waves without a key: exp(-inf) = 0
+                        const float4 oi = *reinterpret_cast<const float4*>(o_s + i * 256 + lane * 4);
+                        Lt += wgt * l_s[i];
+                        acc.x = fmaf(wgt, oi.x, acc.x); acc.y = fmaf(wgt, oi.y, acc.y);
+                        acc.z = fmaf(wgt, oi.z, acc.z); acc.w = fmaf(wgt, oi.w, acc.w);
+                    }
+                    const float inv = 1.0f / Lt;
+                    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+                } else { M = -1e30f; Lt = 0.f; }                           // a chunk without keys (or a padding row): weight 0
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // frag position of (row n, k-quad h * 64 + lane) in C's B-operand order
+                const int q = h * 64 + lane;
+                const int fl = (q / KK) * 64 + (((n >> 2) * KK + (q % KK)) * 4 + (n & 3));
+                const int eo = (kRoffOP + ch * R * D) * 4 + fl * 16;
+                rpublish(brs, pc + eo, po + eo, acc);
+                if (lane == 0) {
+                    const int mo = (kRoffML + ((ch * kRMaxRows + n) * 4 + h) * 4) * 4;
+                    rpublish(brs, pc + mo, po + mo, make_float4(M, Lt, 0.f, 0.f));
+                }
+            }
+            stamp_at(l, 1, 1);
+        }
+        // =================== C: merge chunk partials -> attn c_proj -> x' = x + ... ===================
+        {
+            GVC_PHASE_BEGIN();
+            const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
+            const int s0 = wave * NSX;
+            float4 ov[NSX];
+            const float4 bpre = *reinterpret_cast<const float4*>(Lp->proj_b + wg * 4);
+            {
+                pu32x4 raw[NSX];
+                rgather<NSX>(c, brs, pc + kRoffOP * 4 + s0 * 1024 + lane * 16, 1024, raw, 300 + l, NSX <= A.poll_all);
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
+            }
+            if (nch > 1) {                                   // the wave's 32 k-quads lie in head wave / 2
+                const int hh = wave >> 1;
+                pu32x4 ml[1];
+                rgather<1>(c, brs, pc + (kRoffML + ((0 * kRMaxRows + n) * 4 + hh) * 4) * 4, 0, ml, 310 + l);
+                float M = __uint_as_float(ml[0].x), Wt = __uint_as_float(ml[0].y);       // running max, sum of weights (at max M)
+                auto merge = [&](const pu32x4 (&raw)[NSX], float mc, float lc) {
+                    const float Mn = fmaxf(M, mc);
+                    const float wa = Wt * __expf(M - Mn), wb = lc * __expf(mc - Mn);
+                    const float tot = wa + wb;
+                    const float fa = tot > 0.f ? wa / tot : 0.f, fb = tot > 0.f ? wb / tot : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i) {
+                        const float4 oc = as_f4(raw[i]);
+                        ov[i].x = fa * ov[i].x + fb * oc.x; ov[i].y = fa * ov[i].y + fb * oc.y;
+                        ov[i].z = fa * ov[i].z + fb * oc.z; ov[i].w = fa * ov[i].w + fb * oc.w;
+                    }
+                    M = Mn; Wt = tot;
+                };
+                auto chunk_off = [&](int cc) { return pc + (kRoffOP + cc * R * D) * 4 + s0 * 1024 + lane * 16; };
+                auto ml_off = [&](int cc) { return pc + (kRoffML + ((cc * kRMaxRows + n) * 4 + hh) * 4) * 4; };
+                if (nch == 2) {
+                    pu32x4 raw[NSX];
+                    rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
+                    rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
+                    merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
+                } else {                                     // four chunks: chunk 1 on its own, 2 and 3 requested together
+                    pu32x4 raw[NSX], rawb[NSX], mlb[1];
+                    rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
+                    rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i) rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, chunk_off(2), i * 1024, 16);
+                    merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
+                    rgather<NSX>(c, brs, chunk_off(3), 1024, raw, 321 + l);
+                    rgather<1>(c, brs, ml_off(3), 0, mlb, 331 + l);
+                    {   // chunk 2 was requested before chunk 1 was merged: re-request what was still poison then
+                        unsigned spins = 0;
+                        while (true) {
+                            bool again = false;
+#pragma unroll
+                            for (int i = 0; i < NSX; ++i)
+                                if (__any(!rclean(rawb[i]))) { rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, chunk_off(2), i * 1024, 16); again = true; }
+                            if (!again) break;
+                            if (spin_fail(c, spins, 322 + l, 1)) break;
+                        }
+                    }
+                    rgather<1>(c, brs, ml_off(2), 0, ml, 332 + l);
+                    merge(rawb, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
+                    merge(raw, __uint_as_float(mlb[0].x), __uint_as_float(mlb[0].y));
+                }
+            }
+            stamp_at(l, 2, 0);
+            pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            wait_fill(c, fs);
+            {
+                const char* wbase = ring + (size_t)(fs & rmask) * kPSlot + (s0 * STEPB + (lane & LMASK) * 16);
+                float4 wc = *reinterpret_cast<const float4*>(wbase), wn;
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    if (i + 1 < NSX) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, ov[i].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, ov[i].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.z, ov[i].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.w, ov[i].w, acc1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wc = wn;
+                }
+            }
+            {
+                const float4 r = make_float4(kk_sum<R>(acc0[0] + acc1[0]), kk_sum<R>(acc0[1] + acc1[1]), kk_sum<R>(acc0[2] + acc1[2]),
+                                             kk_sum<R>(acc0[3] + acc1[3]));
+                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + 0) * kRMaxRows + n) * 4) = r;
+            }
+            fs += 1;
+            phase_done();
+            cbar(c);
+            if (wave == 0 && lane < R) {
+                const int rn = lane;
+                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + 0) * kRMaxRows + rn) * 4);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) {
+                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + 0) * kRMaxRows + rn) * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                const float4 bi = bpre;
+                const float4 xr = *reinterpret_cast<const float4*>(resid + rn * 4);
+                s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
+                *reinterpret_cast<float4*>(resid + rn * 4) = s;           // x': the residual of phase E
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int fl = (wg / KK) * 64 + (((rn >> 2) * KK + (wg % KK)) * 4 + (rn & 3));
+                const int eo = kRoffX0 * 4 + fl * 16;
+                rpublish(brs, pc + eo, po + eo, s);
+            }
+            stamp_at(l, 2, 1);
+        }
+        // =================== D: LN2 -> c_fc rows -> gelu_new ===================
+        {
+            GVC_PHASE_BEGIN();
+            const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
+            const int s0 = wave * NSX;
+            float4 xv[NSX];
+            const float4 bpre = *reinterpret_cast<const float4*>(Lp->fc_b + wg * 16 + (wave & 3) * 4);
+            *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) =
+                *reinterpret_cast<const float4*>((lane < 32 ? Lp->ln2_w : Lp->ln2_b) + (s0 * KK + (lane & 31)) * 4);
+            {
+                pu32x4 raw[NSX];
+                rgather<NSX>(c, brs, pc + kRoffX0 * 4 + s0 * 1024 + lane * 16, 1024, raw, 400 + l, NSX <= A.poll_all);
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) xv[i] = as_f4(raw[i]);
+            }
+            stamp_at(l, 3, 0);
+            float mean_, rstd_;
+            {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+                const float mw = kk_sum<R>(s) * (1.0f / (float)(NSX * KK * 4));
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    const float a0 = xv[i].x - mw, a1 = xv[i].y - mw, a2 = xv[i].z - mw, a3 = xv[i].w - mw;
+                    m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+                m2 = kk_sum<R>(m2);
+                if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
+                cbar(c);
+                float mean = 0.f;
+#pragma unroll
+                for (int w = 0; w < kPCW; ++w) mean += stat[w * 16 + n];
+                mean *= 1.0f / (float)kPCW;
+                float M2 = 0.f, dv = 0.f;
+#pragma unroll
+                for (int w = 0; w < kPCW; ++w) {
+                    const float dm = stat[w * 16 + n] - mean;
+                    M2 += stat[kPCW * 16 + w * 16 + n];
+                    dv += dm * dm;
+                }
+                const float var = (M2 + dv * (float)(NSX * KK * 4)) * (1.0f / (float)D);
+                rstd_ = 1.0f / sqrtf(var + 1e-5f);
+                mean_ = mean;
+            }
+                        pf32x4 acc[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+            stamp_at(l, 3, 2);
+            wait_fill(c, fs + 3);
+            stamp_at(l, 3, 3);
+            {
+                // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
+                // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
+                const char* wbase = ring + (s0 * STEPB + (lane & LMASK) * 16);
+                const float* gb = gbs + (wave * 64 + kk) * 4;
+                float4 wc[4], wn[4], gc, bc, gn, bn;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) wc[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+                gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
+#pragma unroll
+                for (int i = 0; i < NSX; ++i) {
+                    if (i + 1 < NSX) {
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) wn[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (i + 1) * STEPB);
+                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
+                    }
+                    const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
+                    const float x2 = (xv[i].z - mean_) * rstd_ * gc.z + bc.z, x3 = (xv[i].w - mean_) * rstd_ * gc.w + bc.w;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].x, x0, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].y, x1, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].z, x2, acc[rg], 0, 0, 0);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].w, x3, acc[rg], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) wc[rg] = wn[rg];
+                    gc = gn; bc = bn;
+                }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 r = make_float4(kk_sum<R>(acc[rg][0]), kk_sum<R>(acc[rg][1]), kk_sum<R>(acc[rg][2]), kk_sum<R>(acc[rg][3]));
+                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + rg) * kRMaxRows + n) * 4) = r;
+            }
+            fs += 4;
+            phase_done();
+            cbar(c);
+            if (wave < 4 && lane < R) {
+                const int rg = wave, rn = lane;
+                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + rg) * kRMaxRows + rn) * 4);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) {
+                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + rg) * kRMaxRows + rn) * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                const float4 bi = bpre;
+                s.x = gelu_new(s.x + bi.x); s.y = gelu_new(s.y + bi.y); s.z = gelu_new(s.z + bi.z); s.w = gelu_new(s.w + bi.w);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int q = wg * 4 + rg;                   // k-quad of the hidden units [16 wg + 4 rg, +4)
+                const int fl = (q / KK) * 64 + (((rn >> 2) * KK + (q % KK)) * 4 + (rn & 3));
+                const int eo = kRoffHH * 4 + fl * 16;
+                rpublish(brs, pc + eo, po + eo, s);
+            }
+            stamp_at(l, 3, 1);
+        }
+        // =================== E: mlp c_proj -> x = x' + ... ===================
+        {
+            GVC_PHASE_BEGIN();
+            const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
+            const int s0 = wave * NSH;
+            const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + wg * 4);
+            pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            constexpr int CHK = NSH < 16 ? NSH : 16;
+#pragma unroll 1
+            for (int cs = 0; cs < NSH; cs += CHK) {
+                pu32x4 raw[CHK];
+                rgather<CHK>(c, brs, pc + kRoffHH * 4 + (s0 + cs) * 1024 + lane * 16, 1024, raw, 500 + l, CHK <= A.poll_all);
+                if (cs == 0) stamp_at(l, 4, 0);
+                const unsigned boff = (unsigned)(s0 + cs) * STEPB;           // byte offset inside the 64 KiB group
+                wait_fill(c, fs + ((boff + CHK * STEPB - 1) >> 14));
+                {
+                    // (a chunk of <= 16 steps lies inside one 16 KiB ring slot: 16 steps x 256 / 512 bytes <= 8 KiB)
+                    const char* wbase = ring + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot + ((boff & 16383u) + (lane & LMASK) * 16);
+                    float4 wc = *reinterpret_cast<const float4*>(wbase), wn;
+#pragma unroll
+                    for (int i = 0; i < CHK; ++i) {
+                        if (i + 1 < CHK) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
+                        const float4 hv = as_f4(raw[i]);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, hv.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, hv.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.z, hv.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.w, hv.w, acc1, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        wc = wn;
+                    }
+                }
+            }
+            {
+                const float4 r = make_float4(kk_sum<R>(acc0[0] + acc1[0]), kk_sum<R>(acc0[1] + acc1[1]), kk_sum<R>(acc0[2] + acc1[2]),
+                                             kk_sum<R>(acc0[3] + acc1[3]));
+                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + 0) * kRMaxRows + n) * 4) = r;
+            }
+            fs += 4;
+            phase_done();
+            cbar(c);
+            if (wave == 0 && lane < R) {
+                const int rn = lane;
+                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + 0) * kRMaxRows + rn) * 4);
+#pragma unroll
+                for (int w = 1; w < kPCW; ++w) {
+                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + 0) * kRMaxRows + rn) * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                const float4 bi = bpre;
+                const float4 xr = *reinterpret_cast<const float4*>(resid + rn * 4);
+                s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int fl = (wg / KK) * 64 + (((rn >> 2) * KK + (wg % KK)) * 4 + (rn & 3));
+                const int eo = kRoffX1 * 4 + fl * 16;
+                rpublish(brs, pc + eo, po + eo, s);
+                if (l == A.n_layer - 1 && rn < A.rows) *reinterpret_cast<float4*>(A.x + (size_t)rn * D + wg * 4) = s;
+            }
+            stamp_at(l, 4, 1);
+        }
+    }
+#undef GVC_PHASE_BEGIN
+}
+
+}  // namespace gvc

@@ -130,6 +130,10 @@ class GptEngine:
         """which decode step the last generate() call replayed (include/genvc_hip.h: gvc_gpt_decode_variant)"""
         return int(lib().gvc_gpt_decode_variant(self._h))
 
+    def rows_step_launches(self):
+        """one-launch rows steps issued so far (include/genvc_hip.h: gvc_gpt_rows_step_launches)"""
+        return int(lib().gvc_gpt_rows_step_launches(self._h))
+
     def time_kernel(self, which, slots, tok, n_steps):
         """(mean us per launch, launches) of one kernel class of the decode step, launched back to back"""
         avg, n = C.c_float(), C.c_int32()

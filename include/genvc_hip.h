@@ -166,8 +166,12 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
 
 /* Which decode step the last gvc_gpt_generate call replayed (diagnostic): 0 none yet, 1 launch-per-phase with split-key attention,
  * 2 launch-per-phase with the fused short-context attention launch, 3 the one-launch step (one fp32 stream), 4 the MFMA rows path
- * (>= 5 streams). */
+ * (>= 5 streams, launch per phase), 5 the one-launch rows step (2..16 fp32 streams, csrc/persist_rows.h). */
 int gvc_gpt_decode_variant(gvc_gpt* ctx);
+/* Diagnostic: how many one-launch rows steps (csrc/persist_rows.h: 2..16 rows that continue cached sequences -- batched decode
+ * steps, the uncached rows of a streaming chunk's prefill) this context has issued; a step captured into the generation loop's
+ * graph counts once.  Tests use it to prove which path served a call. */
+long long gvc_gpt_rows_step_launches(gvc_gpt* ctx);
 
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head
