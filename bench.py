@@ -364,7 +364,16 @@ def main():
         kvb = 2 if args.weights == "bf16_kv" else 4
         fresh()
         whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)          # launch-per-phase step (the fallback path; the bf16 contexts' path)
-        one_launch = args.weights == "fp32" and os.environ.get("GVC_PERSIST", "1") != "0"
+        # which step the B = 1 generation loop really replays is the engine's to say (3 = the one-launch step): a device with fewer
+        # than 256 CUs, a failed LDS opt-in, GVC_PERSIST=0 or bf16 storage all leave it on the launch-per-phase step
+        probe_ids = torch.ones(1, wl.P + 1 + 16, device=device, dtype=torch.int32)
+        probe_ids[:, wl.P] = wl.dims["start_audio_token"]
+        fresh()
+        wl.eng.generate(s1, probe_ids, torch.full((1,), wl.P + 1, device=device, dtype=torch.int32), torch.zeros(1, device=device, dtype=torch.int32),
+                        wl.sp, 0, 2, torch.zeros(1, 2, device=device, dtype=torch.int32), torch.zeros(1, 2, wl.dims["d_model"], device=device),
+                        max_keys=wl.P + 4)
+        torch.cuda.synchronize()
+        one_launch = wl.eng.decode_variant() == 3
         kern = []
         if one_launch:
             # the one-stream decode step is ONE launch (csrc/persist_kernel.h) = 80 % of the utterance: it IS the dominant kernel.
@@ -372,7 +381,7 @@ def main():
             fresh()
             step_us, n = wl.eng.time_kernel(7, s1, tok, 24)
             s_mid = wl.P + 1 + 12
-            kern.append({"kernel": "k_decode_persist<4> (whole decode step of one stream, one launch)", "avg_us": step_us,
+            kern.append({"kernel": f"k_decode_persist<{wl.dims['d_model'] // 256}> (whole decode step of one stream, one launch)", "avg_us": step_us,
                          "launches_per_step": 1, "bytes": step_bytes(wl.dims, s_mid, wb, kvb)})
             dom = 0
         else:

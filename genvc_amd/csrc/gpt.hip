@@ -106,9 +106,10 @@ __global__ void k_prefix_rows(float* out, const float* cond, int n_cond, const i
 
 // one workgroup per stream: x[b] = mel_embedding[tok[b]] + mel_pos_embedding[mel_pos[slot[b]]]  (gpt_inference.py:92-96)
 __global__ void k_embed_decode_rows(float* x, const int32_t* tok, const int32_t* slots, GptState st, const float* mel_emb,
-                                    const float* mel_pos, int d) {
+                                    const float* mel_pos, int d, int vocab) {
     const int b = blockIdx.x;
-    const float* e = mel_emb + (size_t)tok[b] * d;
+    // (clamped: after a step that produced garbage -- a timed-out hand-off -- the sampler may hand over any id)
+    const float* e = mel_emb + (size_t)min(max(tok[b], 0), vocab - 1) * d;
     const float* p = mel_pos + (size_t)st.mel_pos[slots[b]] * d;
     float* dst = x + (size_t)b * d;
     for (int k = threadIdx.x * 4; k < d; k += blockDim.x * 4) {
@@ -244,6 +245,7 @@ struct gvc_gpt {
     int p_ring_slots = 0, p_ascr = 0, p_hvec = 0;
     size_t p_lds = 0;
     int last_variant = 0;             // decode variant of the last gvc_gpt_generate call (gvc_gpt_decode_variant)
+    int fallbacks = 0;                // hand-off timeouts that switched the one-launch steps off (gvc_gpt_health)
     // one-launch block stack for 2..16 rows (persist_rows.h): batched decode steps, cached chunk prefills
     int persist_rows = 1;             // GVC_PERSIST_ROWS=0: those calls keep the launch-per-phase rows path
     int persist_rows_min = 2;         // GVC_PERSIST_ROWS_MIN: smallest row count served
@@ -623,6 +625,14 @@ static bool fused_ok(const gvc_gpt* c, int B, int max_keys) {
 // ---------------------------------------------------------------------------------------------
 // one-launch decode step (persist_kernel.h)
 // ---------------------------------------------------------------------------------------------
+// test hook (tests/test_gpu_gpt.py): GVC_PERSIST_TEST_GRID=255 launches the one-launch steps one workgroup short, which is what a
+// non-resident workgroup looks like to the others -- every hand-off times out and the fallback of check_ready must take over
+static int persist_test_grid() {
+    const char* e = getenv("GVC_PERSIST_TEST_GRID");        // (read per launch: a test sets and clears it inside one process)
+    const int g = e ? atoi(e) : kPG;
+    return g > 0 && g <= kPG ? g : kPG;
+}
+
 template <int ND>
 static int persist_set_attr(size_t lds) {
     GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_decode_persist<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -638,7 +648,7 @@ static bool persist_ok(const gvc_gpt* c, int B) {
 
 // buffers and the per-layer pointer table; called outside stream capture (synchronous copies)
 static int persist_prepare(gvc_gpt* c) {
-    if (c->p_layers) return GVC_OK;
+    if (c->p_layers || !c->persist) return GVC_OK;
     const int d = c->dm.d_model, L = c->dm.n_layer, H = c->dm.n_head;
     std::vector<PersistLayer> t(L);
     for (int l = 0; l < L; ++l) {
@@ -648,25 +658,39 @@ static int persist_prepare(gvc_gpt* c) {
         p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b; p.fc_w = ly.fc_w; p.fc_b = ly.fc_b; p.p2_w = ly.p2_w; p.p2_b = ly.p2_b;
         p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
     }
+    // Anything the device refuses here (memory, the LDS opt-in, residency of one workgroup per CU) switches the one-launch step off
+    // for this context -- the launch-per-phase step serves it -- instead of failing the caller's decode / generate call; the
+    // buffers are allocated once (a second call after a failure finds the path off and returns before this point).
+    auto unavailable = [&]() {
+        for (void** p : {(void**)&c->p_gran, (void**)&c->p_epoch, (void**)&c->p_dbg})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        (void)hipGetLastError();
+        c->persist = 0;
+        return GVC_OK;
+    };
     const size_t ngran = persist_granules(d, H);
-    GVC_CHECK_HIP(hipMalloc((void**)&c->p_gran, ngran * sizeof(pu64)));
-    GVC_CHECK_HIP(hipMemset(c->p_gran, 0, ngran * sizeof(pu64)));
-    GVC_CHECK_HIP(hipMalloc((void**)&c->p_epoch, 4 * sizeof(unsigned)));
-    GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned)));
+    if (hipMalloc((void**)&c->p_gran, ngran * sizeof(pu64)) != hipSuccess || hipMemset(c->p_gran, 0, ngran * sizeof(pu64)) != hipSuccess ||
+        hipMalloc((void**)&c->p_epoch, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned)) != hipSuccess)
+        return unavailable();
     if (getenv("GVC_PERSIST_STAMPS")) {
-        GVC_CHECK_HIP(hipMalloc((void**)&c->p_dbg, (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long)));
-        GVC_CHECK_HIP(hipMemset(c->p_dbg, 0, (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long)));
+        const size_t nb = (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long);
+        if (hipMalloc((void**)&c->p_dbg, nb) != hipSuccess || hipMemset(c->p_dbg, 0, nb) != hipSuccess) return unavailable();
     }
     const int ng_hd = kPCW * 256;                       // lane-group states of the attention phase: [kPCW * 64 / (hd / 4)][hd]
     c->p_hvec = 4 * d > d + ng_hd ? 4 * d : d + ng_hd;
     c->p_ascr = 3 * c->hd + 64;
     const size_t other = ((size_t)c->p_hvec + d + c->p_ascr) * sizeof(float) + kCtlWords * sizeof(unsigned);
+    // the ring takes what the device's opt-in LDS limit leaves (160 KiB on gfx950: 8 slots)
+    int dev_id = 0, lds_optin = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeSharedMemPerBlockOptin, dev_id) != hipSuccess || lds_optin <= 0)
+        lds_optin = 64 * 1024;
     c->p_ring_slots = 8;
-    while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > 160 * 1024) c->p_ring_slots >>= 1;
+    while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > (size_t)lds_optin) c->p_ring_slots >>= 1;
     c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
-    int rc;
-    if ((rc = persist_set_attr<1>(c->p_lds)) || (rc = persist_set_attr<2>(c->p_lds)) || (rc = persist_set_attr<3>(c->p_lds)) ||
-        (rc = persist_set_attr<4>(c->p_lds))) return rc;
+    if (c->p_lds > (size_t)lds_optin || c->p_ring_slots < 4) return unavailable();
+    if (persist_set_attr<1>(c->p_lds) || persist_set_attr<2>(c->p_lds) || persist_set_attr<3>(c->p_lds) || persist_set_attr<4>(c->p_lds))
+        return unavailable();
     // one workgroup per CU must fit (registers, LDS): otherwise the one-launch step is switched off for this context
     int per_cu = 0;
     const int nd = d / 256;
@@ -674,14 +698,13 @@ static int persist_prepare(gvc_gpt* c) {
                   : nd == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<3>, kPThreads, c->p_lds)
                   : nd == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<2>, kPThreads, c->p_lds)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<1>, kPThreads, c->p_lds);
-    if (oe != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        c->persist = 0;
-        return GVC_OK;
-    }
+    if (oe != hipSuccess || per_cu < 1) return unavailable();
     PersistLayer* dev = nullptr;
-    GVC_CHECK_HIP(hipMalloc((void**)&dev, L * sizeof(PersistLayer)));
-    GVC_CHECK_HIP(hipMemcpy(dev, t.data(), L * sizeof(PersistLayer), hipMemcpyHostToDevice));
+    if (hipMalloc((void**)&dev, L * sizeof(PersistLayer)) != hipSuccess ||
+        hipMemcpy(dev, t.data(), L * sizeof(PersistLayer), hipMemcpyHostToDevice) != hipSuccess) {
+        if (dev) (void)hipFree(dev);
+        return unavailable();
+    }
     c->p_layers = dev;
     return GVC_OK;
 }
@@ -699,10 +722,11 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr; A.hvec_floats = c->p_hvec;
     A.dbg = c->p_dbg;
     const int nd = c->dm.d_model / 256;
-    if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
-    else if (nd == 3) hipLaunchKernelGGL((k_decode_persist<3>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
-    else if (nd == 2) hipLaunchKernelGGL((k_decode_persist<2>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
-    else hipLaunchKernelGGL((k_decode_persist<1>), dim3(kPG), dim3(kPThreads), c->p_lds, s, A);
+    const int grid = persist_test_grid();
+    if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
+    else if (nd == 3) hipLaunchKernelGGL((k_decode_persist<3>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
+    else if (nd == 2) hipLaunchKernelGGL((k_decode_persist<2>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
+    else hipLaunchKernelGGL((k_decode_persist<1>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
@@ -783,8 +807,8 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
     A.poll_all = poll_all;
     A.split1 = c->r_split1; A.split2 = c->r_split2;
-    if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8>), dim3(kPG), dim3(kPThreads), c->r_lds, s, A);
-    else hipLaunchKernelGGL((k_rows_persist<16>), dim3(kPG), dim3(kPThreads), c->r_lds, s, A);
+    if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8>), dim3(persist_test_grid()), dim3(kPThreads), c->r_lds, s, A);
+    else hipLaunchKernelGGL((k_rows_persist<16>), dim3(persist_test_grid()), dim3(kPThreads), c->r_lds, s, A);
     GVC_LAUNCH_CHECK();
     c->r_launches += 1;
     return GVC_OK;
@@ -867,7 +891,7 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
                        int32_t* step_ctr, hipStream_t s, int key_chunks = 1) {
     const int d = c->dm.d_model;
     int rc;
-    hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d);
+    hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d, c->dm.vocab);
     GVC_LAUNCH_CHECK();
     if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len, key_chunks))) return rc;
     for (int g = 0; g < B; g += 8) {
@@ -888,9 +912,24 @@ static int check_ready(gvc_gpt* c) {
     GVC_REQUIRE(dev_err != 950 && dev_err != 951, GVC_ERR_STATE,
                 "a decode step ran with a full %s (max_seq %d, max_mel_pos %d): its position was not advanced; reset the slot",
                 dev_err == 950 ? "KV cache" : "mel position table", c->dm.max_seq, c->dm.max_mel_pos);
-    GVC_REQUIRE(dev_err == 0, GVC_ERR_STATE,
-                "an in-kernel hand-off of the one-launch decode step timed out (code %d: were all 256 workgroups resident?); "
-                "the context must be re-created, or run with GVC_PERSIST=0", dev_err);
+    if (dev_err != 0) {
+        // A hand-off of a one-launch step timed out: not all 256 workgroups were resident (another process or stream held CUs).
+        // The call that timed out has produced garbage and this call reports it ONCE; the context itself stays usable -- both
+        // one-launch steps are switched off, the captured step graphs (which contain them) are dropped, the hand-off buffers are
+        // re-initialised -- and every later call runs on the launch-per-phase paths.
+        (void)hipDeviceSynchronize();
+        c->persist = 0;
+        for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
+        c->graphs.clear();
+        if (c->r_bufs) (void)hipMemset(c->r_bufs, 0xff, rows_buf_bytes());
+        if (c->p_epoch) (void)hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned));
+        *c->seam_err_host = 0;
+        c->fallbacks += 1;
+        set_error("an in-kernel hand-off of a one-launch decode step timed out (code %d: were all 256 workgroups resident?); the outputs "
+                  "of the previous decode / generate / cached-prefill call are invalid.  The context has switched to the launch-per-phase "
+                  "paths and stays usable: reset the affected slots and repeat the call", dev_err);
+        return GVC_ERR_STATE;
+    }
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
                 gvc_gpt_missing_weights(c));
     return GVC_OK;
@@ -1306,6 +1345,11 @@ extern "C" int gvc_gpt_time_kernel(gvc_gpt* c, int32_t which, const int32_t* slo
 
 extern "C" int gvc_gpt_decode_variant(gvc_gpt* c) { return c ? c->last_variant : 0; }
 extern "C" long long gvc_gpt_rows_step_launches(gvc_gpt* c) { return c ? c->r_launches : 0; }
+
+// To be called after the caller has synchronised the stream of a decode / generate / cached-prefill call: 0 when that work ran
+// cleanly; otherwise the state error of check_ready (a timed-out hand-off has switched the context to the launch-per-phase paths,
+// a full KV cache / position table).  Without it such an error surfaces on the next library call.
+extern "C" int gvc_gpt_health(gvc_gpt* c) { return check_ready(c); }
 
 // debug: copy the in-kernel timestamps of the GEMV launches since the last call (GVC_DEBUG_STAMPS=1)
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {

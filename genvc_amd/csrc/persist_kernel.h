@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
 
         // ---- x = mel_embedding[tok] + mel_pos_embedding[pos]  (gpt_inference.py:92-96), by every workgroup ----
         if (wave < ND) {
-            const float* e = A.mel_emb + (size_t)A.tok_in[0] * D + wave * 256 + lane * 4;
+            const float* e = A.mel_emb + (size_t)min(max(A.tok_in[0], 0), A.vocab - 1) * D + wave * 256 + lane * 4;
             const float* p = A.mel_pos + (size_t)A.st.mel_pos[slot] * D + wave * 256 + lane * 4;
             const float4 ev = *reinterpret_cast<const float4*>(e), pv = *reinterpret_cast<const float4*>(p);
             *reinterpret_cast<float4*>(xvec + wave * 256 + lane * 4) = make_float4(ev.x + pv.x, ev.y + pv.y, ev.z + pv.z, ev.w + pv.w);

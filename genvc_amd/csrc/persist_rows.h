@@ -148,7 +148,11 @@ template <int R>
 __device__ __forceinline__ float kk_sum(float v) {
     v += dpp_mov<0x124>(v);          // row_ror:4
     v += dpp_mov<0x128>(v);          // row_ror:8
-    if (R <= 8) v += __shfl_xor(v, 16);
+    if (R <= 8) {                    // + the other 16-lane row of the pair: v_permlane16_swap instead of a trip through the LDS crossbar
+        const unsigned u = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     if (R <= 4) v += __shfl_xor(v, 32);
     return v;
 }
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
                     rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
                     merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
-                } else {                                     // four chunks: chunk 1 on its own, 2 and 3 requested together
+                } else if constexpr (NSX <= 4) {             // four chunks, 8 rows: chunk 2 requested while chunk 1 is merged
                     pu32x4 raw[NSX], rawb[NSX], mlb[1];
                     rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
                     rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
@@ -578,6 +582,14 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     rgather<1>(c, brs, ml_off(2), 0, ml, 332 + l);
                     merge(rawb, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
                     merge(raw, __uint_as_float(mlb[0].x), __uint_as_float(mlb[0].y));
+                } else {                                     // four chunks, 16 rows (registers): one after the other
+#pragma unroll 1
+                    for (int cc = 1; cc < 4; ++cc) {
+                        pu32x4 raw[NSX];
+                        rgather<NSX>(c, brs, chunk_off(cc), 1024, raw, 320 + l);
+                        rgather<1>(c, brs, ml_off(cc), 0, ml, 330 + l);
+                        merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
+                    }
                 }
             }
             stamp_at(l, 2, 0);
@@ -741,22 +753,51 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int s0 = wave * NSH;
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + wg * 4);
             pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            constexpr int CHK = NSH < 16 ? NSH : 16;
-#pragma unroll 1
-            for (int cs = 0; cs < NSH; cs += CHK) {
-                pu32x4 raw[CHK];
-                rgather<CHK>(c, brs, pc + kRoffHH * 4 + (s0 + cs) * 1024 + lane * 16, 1024, raw, 500 + l, CHK <= A.poll_all);
-                if (cs == 0) stamp_at(l, 4, 0);
-                const unsigned boff = (unsigned)(s0 + cs) * STEPB;           // byte offset inside the 64 KiB group
-                wait_fill(c, fs + ((boff + CHK * STEPB - 1) >> 14));
+            // the wave's K-slice of h: NSH 16-byte pieces per lane.  One sentinel piece is polled, then EVERYTHING else is requested at
+            // once (16 rows: 32 pieces = 128 registers) and each 16-step chunk is completed (dirty pieces re-requested) right before
+            // its MFMAs: one memory round trip for the whole slice once the data is there
+            constexpr int NCK = NSH / 16;
+            static_assert(NSH % 16 == 0, "the mlp c_proj slice of a wave is cut in 16-step chunks");
+            pu32x4 raw[NCK][16];
+            const int goff = pc + kRoffHH * 4 + s0 * 1024 + lane * 16;
+            {
+                unsigned spins = 0;
+                while (true) {
+                    raw[0][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, 0, 16);
+                    if (__all(rclean(raw[0][0]))) break;
+                    if (spin_fail(c, spins, 500 + l, 1)) break;
+                }
+            }
+#pragma unroll
+            for (int ck = 0; ck < NCK; ++ck) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (ck + i > 0) raw[ck][i] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, (ck * 16 + i) * 1024, 16);
+            }
+#pragma unroll
+            for (int ck = 0; ck < NCK; ++ck) {
                 {
-                    // (a chunk of <= 16 steps lies inside one 16 KiB ring slot: 16 steps x 256 / 512 bytes <= 8 KiB)
+                    unsigned spins = 0;
+                    while (true) {
+                        bool again = false;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (__any(!rclean(raw[ck][i]))) { raw[ck][i] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, (ck * 16 + i) * 1024, 16); again = true; }
+                        if (!again) break;
+                        if (spin_fail(c, spins, 510 + l, 1)) break;
+                    }
+                }
+                if (ck == 0) stamp_at(l, 4, 0);
+                const unsigned boff = (unsigned)(s0 + ck * 16) * STEPB;      // byte offset inside the 64 KiB group
+                wait_fill(c, fs + ((boff + 16 * STEPB - 1) >> 14));
+                {
+                    // (a chunk of 16 steps lies inside one 16 KiB ring slot: 16 steps x 256 / 512 bytes <= 8 KiB)
                     const char* wbase = ring + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot + ((boff & 16383u) + (lane & LMASK) * 16);
                     float4 wc = *reinterpret_cast<const float4*>(wbase), wn;
 #pragma unroll
-                    for (int i = 0; i < CHK; ++i) {
-                        if (i + 1 < CHK) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
-                        const float4 hv = as_f4(raw[i]);
+                    for (int i = 0; i < 16; ++i) {
+                        if (i + 1 < 16) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
+                        const float4 hv = as_f4(raw[ck][i]);
                         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, hv.x, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, hv.y, acc1, 0, 0, 0);
                         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.z, hv.z, acc0, 0, 0, 0);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kSampThreads) void k_sample(SampleCall cv, const Sa
         if (tid == 0) {
             for (int w = 1; w < kSampThreads / 64; ++w)
                 if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; }
-            s_tok = bi;
+            s_tok = bi < V ? bi : 0;          // (all scores NaN -- the step before produced garbage: any valid id, never an out-of-range one)
         }
         __syncthreads();
         tok = s_tok;

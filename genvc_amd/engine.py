@@ -130,6 +130,11 @@ class GptEngine:
         """which decode step the last generate() call replayed (include/genvc_hip.h: gvc_gpt_decode_variant)"""
         return int(lib().gvc_gpt_decode_variant(self._h))
 
+    def health(self):
+        """after a synchronisation: raises if the work just finished hit a hand-off timeout (the context then continues on the
+        launch-per-phase paths) or a full KV cache (include/genvc_hip.h: gvc_gpt_health)"""
+        check(lib().gvc_gpt_health(self._h), "health")
+
     def rows_step_launches(self):
         """one-launch rows steps issued so far (include/genvc_hip.h: gvc_gpt_rows_step_launches)"""
         return int(lib().gvc_gpt_rows_step_launches(self._h))

@@ -139,6 +139,9 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
                 all_latents.append(latent)
             except StopIteration:
                 is_end = True
+            # DIVERGENCE from the reference, on purpose: inference_utils.py:192-196 runs `torch.cat(all_latents)` whenever `is_end` is
+            # set, so a segment whose token count is a multiple of stream_chunk_size (the last group was flushed by the count rule,
+            # then StopIteration arrives with nothing pending) crashes there on torch.cat([]).  Here an empty tail is skipped.
             if (is_end and all_latents) or (stream_chunk_size > 0 and len(last_tokens) >= stream_chunk_size):
                 acoustic = torch.cat(all_latents, dim=0)[None, :]       # EOS-step latent included (:189-196)
                 chunks_lat.append(acoustic)

@@ -178,7 +178,9 @@ class GPT(nn.Module):
             self.engine.generate(st["slots"], st["ids"], st["ids_len"], st["finished"], st["params"], st["done"], n,
                                  st["toks"], st["lats"], max_keys=st["n0"] + st["done"] + n)
             st["done"] += n
-        return bool(st["finished"].all().item()) or st["done"] >= st["max_new"]
+        end = bool(st["finished"].all().item()) or st["done"] >= st["max_new"]
+        self.engine.health()          # (the .item() above synchronised: a hand-off timeout of these steps surfaces here, not a call later)
+        return end
 
     @torch.inference_mode()
     def generate(self, cond_latents, text_inputs, **generate_kwargs):
@@ -253,7 +255,9 @@ class GPT(nn.Module):
             n = min(group, max_new - done)
             self.engine.generate(slots, ids, ids_len, finished, params, done, n, toks, lats, max_keys=max(n0s) + done + n)
             done += n
-            if bool(finished.all().item()):
+            stop = bool(finished.all().item())
+            self.engine.health()
+            if stop:
                 break
         out = []
         for lo, hi in spans:

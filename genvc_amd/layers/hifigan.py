@@ -52,7 +52,23 @@ class HiFiGAN(nn.Module):
 
     # frames of context kept on each side of a window of a long input: the generator's receptive field is +-13 input frames
     # (conv_pre 3, the k = 7 / dilation 12 ResBlock of the first upsampling stage 6, the rest < 1 each)
-    WINDOW_OVERLAP = 32
+    def receptive_frames(self):
+        """input frames on either side that can reach one output sample (reference hifigan.py:119-157,218-233: conv_pre k = 7, per
+        stage a transposed conv of kernel k_up at the stage's output rate and ResBlock2s whose two dilated convs reach
+        (k - 1) / 2 * d samples each; conv_post k = 7): 11.5 frames for the trained configuration"""
+        rf, cum = 3.0, 1.0
+        for r, ku in zip(self.cfg["upsample_rates"], self.cfg["upsample_kernel_sizes"]):
+            cum *= r
+            reach = max(sum((k - 1) // 2 * d for d in ds) for k, ds in zip(self.cfg["resblock_kernel_sizes"], self.cfg["resblock_dilation_sizes"]))
+            rf += (ku / 2.0 + reach) / cum
+        return rf + 3.0 / cum
+
+    @property
+    def window_overlap(self):
+        """frames re-computed on either side of a window's kept interior: the receptive field rounded up to a multiple of 8 plus
+        a margin (32 for the trained configuration)"""
+        import math
+        return int(math.ceil((self.receptive_frames() + 8) / 8.0)) * 8 + 8
 
     @torch.inference_mode()
     def forward(self, x):
@@ -62,9 +78,12 @@ class HiFiGAN(nn.Module):
         if self._engine is None:
             self.bind()
         x = x.to(torch.float32)
-        T, cap, ov = x.shape[-1], self._engine.max_frames, self.WINDOW_OVERLAP
+        T, cap, ov = x.shape[-1], self._engine.max_frames, self.window_overlap
         if T <= cap:
             return self._engine.forward(x.contiguous())
+        if cap <= 2 * ov + 8:
+            raise ValueError(f"HiFiGAN: {T} frames exceed the engine's buffers ({cap} frames) and those are too small for overlapping "
+                             f"windows (receptive field {self.receptive_frames():.1f} frames, overlap {ov}): bind(max_frames=...) larger")
         up = 1
         for r in self.cfg["upsample_rates"]:
             up *= r

@@ -52,7 +52,7 @@ typedef struct gvc_gpt gvc_gpt;
 typedef struct gvc_gpt_dims {
     int32_t n_layer;      /* gpt_layers */
     int32_t d_model;      /* gpt_n_model_channels; multiple of 256 */
-    int32_t n_head;       /* gpt_n_heads; head_dim = d_model / n_head must be 64 or 256 */
+    int32_t n_head;       /* gpt_n_heads; head_dim = d_model / n_head must be 64, 128 or 256 */
     int32_t vocab;        /* gpt_num_audio_tokens (1026) */
     int32_t max_mel_pos;  /* rows of mel_pos_embedding (608) */
     int32_t max_text_pos; /* rows of text_pos_embedding (404) */
@@ -172,6 +172,13 @@ int gvc_gpt_decode_variant(gvc_gpt* ctx);
  * steps, the uncached rows of a streaming chunk's prefill) this context has issued; a step captured into the generation loop's
  * graph counts once.  Tests use it to prove which path served a call. */
 long long gvc_gpt_rows_step_launches(gvc_gpt* ctx);
+/* Health of the work a caller has just synchronised (no reference counterpart: the reference has no in-kernel hand-offs).  The
+ * one-launch steps need all 256 workgroups co-resident; when another process or stream holds CUs a hand-off times out (~0.2 s,
+ * bounded spins), the step's outputs are garbage and a device-visible word records it.  This call -- and, failing that, the next
+ * library call -- then returns GVC_ERR_STATE ONCE, having switched the context to the launch-per-phase paths (captured graphs
+ * dropped, hand-off buffers re-initialised): the context stays usable, the caller resets the affected slots and repeats the work.
+ * Also reports a full KV cache / mel position table (see gvc_gpt_reset_slots).  GVC_OK otherwise. */
+int gvc_gpt_health(gvc_gpt* ctx);
 
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head

@@ -171,3 +171,32 @@ def test_rows_step_full_size_replicated_stream_matches_reference_141_steps(gold,
     assert np.array_equal(toks.numpy(), np.tile(g["tokens"], (reps, 1))), "batched greedy ids differ from the reference"
     np.testing.assert_allclose(lats[:1, :, :32].numpy(), g["latents_slice"], atol=1e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("B", [1, 6], ids=["one_stream_step", "rows_step"])
+def test_hand_off_timeout_falls_back_to_launch_per_phase(B, monkeypatch):
+    """a one-launch step whose workgroups are not all resident (simulated: the grid is launched one workgroup
+    short) times out in its bounded spins; the error is reported once (engine.health() / the next library call), the context
+    switches itself to the launch-per-phase paths and the repeated work is correct"""
+    from test_gpu_gpt import run_generate
+    from genvc_amd._lib import GenvcHipError
+    from oracle import genvc_oracle as O
+    dims, w, eng = _engine(WIDE2, 3, 8)
+    wc = {k: v.cpu() for k, v in w.items()}
+    cond = synth.uniform(5, "cond", (B, 32, 1024), 1.0)
+    codes = synth.integers(5, "codes", (B, 11), 256)
+    n = 6
+    monkeypatch.setenv("GVC_PERSIST_TEST_GRID", "255")
+    run_generate(eng, dims, cond, codes, n)                   # garbage: one workgroup never publishes
+    assert eng.decode_variant() == (3 if B == 1 else 5)
+    torch.cuda.synchronize()
+    with pytest.raises(GenvcHipError, match="timed out"):
+        eng.health()
+    monkeypatch.delenv("GVC_PERSIST_TEST_GRID")
+    eng.health()                                              # reported once; the context is usable again
+    _, toks, lats = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() in (1, 2, 4)                  # launch-per-phase paths
+    ref_t, ref_l, _ = O.generate(wc, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    assert torch.equal(toks.long(), ref_t)
+    np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=1e-4)
+    eng.close()
