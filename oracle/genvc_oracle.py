@@ -86,6 +86,44 @@ def mel_spectrogram_dft64(wav, mel_norms):
     return np.stack(out)
 
 
+def resample(wav, orig_sr, new_sr, lowpass_filter_width=6, rolloff=0.99):
+    """Row f2: `utils.load_audio` -> `torchaudio.functional.resample(audio, lsr, sampling_rate)` (/root/reference/utils.py:53-62).
+    torchaudio (pinned 2.3.0, README.md:43) is absent from this image: PARITY UNPINNED against torchaudio itself.  This restates
+    its published algorithm (`_get_sinc_resample_kernel` + `_apply_sinc_resample_kernel`, default `sinc_interp_hann`,
+    lowpass_filter_width 6, rolloff 0.99; recipe in SURVEY.md 8c) as an explicit polyphase sum in numpy float64:
+        o, n = orig / gcd, new / gcd;  base = min(o, n) * rolloff;  width = ceil(lpw * o / base)
+        output sample m = i * n + j (phase j of input block i) = sum_k x[i * o + k - width] * h_j[k],  k in [0, 2 width + o)
+        h_j[k] = sinc(pi t) * cos^2(pi t / (2 lpw)) * base / o,  t = clamp((k - width) / o - j / n) * base, +-lpw)
+    The kernel is rounded to float32 as torchaudio does (dtype=None branch) and the sums run in float64; zero padding on both
+    sides; output length ceil(n * T / o).  tests/test_oracle.py cross-checks it on band-limited signals against the analytic
+    resampled waveform and scipy.signal.resample_poly (another filter: agreement to the filters' ripple)."""
+    import math
+    import numpy as np
+    x = wav.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(wav) else np.asarray(wav, np.float64)
+    g = math.gcd(int(orig_sr), int(new_sr))
+    o, n = int(orig_sr) // g, int(new_sr) // g
+    if o == n:
+        return torch.from_numpy(x.astype(np.float32))
+    base = min(o, n) * rolloff
+    width = int(math.ceil(lowpass_filter_width * o / base))
+    k = np.arange(-width, width + o, dtype=np.float64) / o                        # [2 width + o]
+    t = (-np.arange(n, dtype=np.float64)[:, None] / n + k[None, :]) * base         # [n, taps]
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    tp = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinc = np.where(tp == 0, 1.0, np.sin(tp) / tp)
+    h = (sinc * window * (base / o)).astype(np.float32).astype(np.float64)         # torchaudio keeps the kernel in float32
+    C, T = x.shape
+    taps = h.shape[1]
+    xp = np.concatenate([np.zeros((C, width)), x, np.zeros((C, width + o))], 1)
+    n_blocks = (xp.shape[1] - taps) // o + 1
+    idx = np.arange(n_blocks)[:, None] * o + np.arange(taps)[None, :]              # [blocks, taps]
+    frames = xp[:, idx]                                                            # [C, blocks, taps]
+    y = np.einsum("cbt,jt->cbj", frames, h).reshape(C, -1)                         # phase j of block i -> sample i n + j
+    return torch.from_numpy(y[:, :int(math.ceil(n * T / o))].astype(np.float32))
+
+
 # ---------------------------------------------------------------------------
 # row 3: Perceiver resampler  (perceiver_encoder.py:225-319, gpt.py:351-373)
 # ---------------------------------------------------------------------------

@@ -356,6 +356,10 @@ def main():
         # the CLI default (seg_len 6 s: Tc = 75, P = 109, 141 steps at 23.4375 tokens/s): one stream whose context grows from
         # 110 to 251 cached positions, across the 128-key boundary where the launch-per-phase step changes its attention variant
         make_gpt(GPT, "full_6s_b1", gcfg.DEFAULT_MODEL_ARGS, seed=2, B=1, Tc=75, n_steps=141, keep_rows=[0, 1, 2, 17, 18, 19, 64, 128, 140])
+    if want("full94"):
+        # the OTHER segment class of a 10 s utterance at seg_len 6 s (BASELINE configs[2]): the 4 s tail, Tc = 50, P = 84, 94 steps;
+        # same weights as full_6s_b1, so one context decodes both classes together (parallel_offline / GPT.generate_groups)
+        make_gpt(GPT, "full_4s_b1", gcfg.DEFAULT_MODEL_ARGS, seed=2, B=1, Tc=50, n_steps=94, keep_rows=[0, 1, 2, 46, 93])
     if want("perceiver"):
         make_perceiver(g_tiny, g_full)
     if want("dvae"):

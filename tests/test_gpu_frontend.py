@@ -103,9 +103,10 @@ def test_hifigan_matches_reference(gold):
         eng.close()
 
 
-def test_resampler_matches_torchaudio_restatement():
-    """row f2: polyphase sinc resampler kernel vs the torch restatement of torchaudio.functional.resample"""
-    from genvc_amd.audio import resample as ref_resample
+def test_resampler_matches_oracle_restatement():
+    """row f2: the polyphase sinc resampler kernel against the ORACLE's float64 restatement of torchaudio.functional.resample
+    (oracle/genvc_oracle.py resample; torchaudio is absent from the image, so parity with torchaudio itself is unpinned)"""
+    from oracle.genvc_oracle import resample as ref_resample
     from genvc_amd.engine import resample
     for orig, new, T in ((96000, 16000, 147486), (96000, 24000, 98835 * 4 // 4 + 3), (22050, 16000, 30000), (16000, 24000, 5000)):
         x = synth.synth_audio(9, f"rs{orig}", T)

@@ -194,3 +194,33 @@ def test_hubert_padding_mask_semantics():
     sparse[:, ::7] = 0.0
     assert not bool(O.hubert_frame_padding_mask(sparse, 49).any())
     assert torch.equal(O.hubert_extract_features(w, c, sparse), O.hubert_extract_features(w, c, sparse, padding_mask=False))
+
+
+@pytest.mark.parametrize("orig,new", [(96000, 16000), (96000, 24000), (22050, 16000), (16000, 24000)])
+def test_resampler_restatement_on_band_limited_signals(orig, new):
+    """row f2 (torchaudio absent: parity unpinned against torchaudio itself): the float64 restatement of its sinc_interp_hann
+    recipe reproduces a band-limited signal sampled at the new rate (interior, filter ripple), agrees with
+    scipy.signal.resample_poly -- another low-pass design -- to the two filters' ripple, has torchaudio's output length and is linear"""
+    import math
+    from scipy.signal import resample_poly
+    T = 6000 * orig // 16000
+    t_in = np.arange(T) / orig
+    freqs, amps = [220.0, 1333.0, 0.35 * min(orig, new) / 2], [0.5, 0.3, 0.2]
+    x = sum(a * np.sin(2 * np.pi * f * t_in + 0.3 * i) for i, (f, a) in enumerate(zip(freqs, amps)))
+    y = O.resample(torch.from_numpy(x[None].astype(np.float32)), orig, new).numpy()[0].astype(np.float64)
+    n_out = int(math.ceil(new * T / orig))
+    assert y.shape[0] == n_out
+    t_out = np.arange(n_out) / new
+    exact = sum(a * np.sin(2 * np.pi * f * t_out + 0.3 * i) for i, (f, a) in enumerate(zip(freqs, amps)))
+    edge = 64
+    assert np.abs(y[edge:-edge] - exact[edge:-edge]).max() < 2e-3
+    g = math.gcd(orig, new)
+    sp = resample_poly(x, new // g, orig // g)
+    m = min(len(sp), n_out)
+    assert np.abs(y[edge:m - edge] - sp[edge:m - edge]).max() < 5e-3
+    # linearity and the product's CPU loader path (an independent torch restatement: conv1d over the same kernel)
+    from genvc_amd.audio import resample as loader_resample
+    x2 = synth.synth_audio(3, "rs", T)
+    a = O.resample(x2, orig, new)
+    np.testing.assert_allclose(O.resample(2.5 * x2, orig, new).numpy(), 2.5 * a.numpy(), atol=1e-6)
+    np.testing.assert_allclose(loader_resample(x2, orig, new).numpy(), a.numpy(), atol=1e-6)
