@@ -633,16 +633,21 @@ static int persist_test_grid() {
     return g > 0 && g <= kPG ? g : kPG;
 }
 
-template <int ND>
-static int persist_set_attr(size_t lds) {
-    GVC_CHECK_HIP(hipFuncSetAttribute((const void*)k_decode_persist<ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    return GVC_OK;
+// the instantiation that serves this context: d_model / 256, bf16 weight storage, bf16 KV cache (bf16 rows are streamed in whole
+// KiB per workgroup and phase, which needs an even d_model / 256)
+typedef void (*persist_fn)(const PersistArgs);
+static persist_fn persist_kernel(const gvc_gpt* c) {
+    const int nd = c->dm.d_model / 256;
+    if (c->kv_bf16) return nd == 4 ? (persist_fn)k_decode_persist<4, 1, 1> : (persist_fn)k_decode_persist<2, 1, 1>;
+    if (c->bf16) return nd == 4 ? (persist_fn)k_decode_persist<4, 1, 0> : (persist_fn)k_decode_persist<2, 1, 0>;
+    return nd == 4 ? (persist_fn)k_decode_persist<4> : nd == 3 ? (persist_fn)k_decode_persist<3> : nd == 2 ? (persist_fn)k_decode_persist<2>
+                                                                                                              : (persist_fn)k_decode_persist<1>;
 }
 
 // one stream, fp32 weights and cache, a full MI355X (one workgroup per CU)
 static bool persist_ok(const gvc_gpt* c, int B) {
     const int d = c->dm.d_model;
-    return c->persist && B == 1 && !c->bf16 && c->n_cu >= kPG && d % 256 == 0 && d <= 1024 &&
+    return c->persist && B == 1 && (!c->bf16 || d == 512 || d == 1024) && c->n_cu >= kPG && d % 256 == 0 && d <= 1024 &&
            (c->hd == 64 || c->hd == 128 || c->hd == 256) && c->dm.n_layer < 500;
 }
 
@@ -656,6 +661,10 @@ static int persist_prepare(gvc_gpt* c) {
         PersistLayer& p = t[l];
         p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_w = ly.qkv_w; p.qkv_b = ly.qkv_b; p.proj_w = ly.proj_w; p.proj_b = ly.proj_b;
         p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b; p.fc_w = ly.fc_w; p.fc_b = ly.fc_b; p.p2_w = ly.p2_w; p.p2_b = ly.p2_b;
+        if (c->bf16) {        // bf16-weights context: the loader streams the row-major bf16 copies (same row order, half the bytes)
+            p.qkv_w = reinterpret_cast<const float*>(ly.qkv_h); p.proj_w = reinterpret_cast<const float*>(ly.proj_h);
+            p.fc_w = reinterpret_cast<const float*>(ly.fc_h); p.p2_w = reinterpret_cast<const float*>(ly.p2_h);
+        }
         p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
     }
     // Anything the device refuses here (memory, the LDS opt-in, residency of one workgroup per CU) switches the one-launch step off
@@ -689,15 +698,11 @@ static int persist_prepare(gvc_gpt* c) {
     while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > (size_t)lds_optin) c->p_ring_slots >>= 1;
     c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
     if (c->p_lds > (size_t)lds_optin || c->p_ring_slots < 4) return unavailable();
-    if (persist_set_attr<1>(c->p_lds) || persist_set_attr<2>(c->p_lds) || persist_set_attr<3>(c->p_lds) || persist_set_attr<4>(c->p_lds))
+    if (hipFuncSetAttribute((const void*)persist_kernel(c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->p_lds) != hipSuccess)
         return unavailable();
     // one workgroup per CU must fit (registers, LDS): otherwise the one-launch step is switched off for this context
     int per_cu = 0;
-    const int nd = d / 256;
-    hipError_t oe = nd == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<4>, kPThreads, c->p_lds)
-                  : nd == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<3>, kPThreads, c->p_lds)
-                  : nd == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<2>, kPThreads, c->p_lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decode_persist<1>, kPThreads, c->p_lds);
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persist_kernel(c), kPThreads, c->p_lds);
     if (oe != hipSuccess || per_cu < 1) return unavailable();
     PersistLayer* dev = nullptr;
     if (hipMalloc((void**)&dev, L * sizeof(PersistLayer)) != hipSuccess ||
@@ -721,12 +726,9 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.logits_out = logits_out; A.latent_out = latent_out; A.step_ctr = step_ctr; A.advance = 1;
     A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr; A.hvec_floats = c->p_hvec;
     A.dbg = c->p_dbg;
-    const int nd = c->dm.d_model / 256;
-    const int grid = persist_test_grid();
-    if (nd == 4) hipLaunchKernelGGL((k_decode_persist<4>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
-    else if (nd == 3) hipLaunchKernelGGL((k_decode_persist<3>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
-    else if (nd == 2) hipLaunchKernelGGL((k_decode_persist<2>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
-    else hipLaunchKernelGGL((k_decode_persist<1>), dim3(grid), dim3(kPThreads), c->p_lds, s, A);
+    if (c->bf16) A.head_w = reinterpret_cast<const float*>(c->head_h);
+    void* kargs[] = {&A};
+    GVC_CHECK_HIP(hipLaunchKernel((const void*)persist_kernel(c), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->p_lds, s));
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
@@ -737,7 +739,7 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
 // ---------------------------------------------------------------------------------------------
 static bool rows_persist_ok(const gvc_gpt* c, int rows, const int32_t* base_len) {
     return c->persist && c->persist_rows && c->r_ready >= 0 && base_len && rows >= c->persist_rows_min && rows <= kRMaxRows &&
-           c->dm.d_model == kRD && c->hd == kRHD && c->dm.n_head == 4 && !c->bf16 && !c->kv_bf16 && c->dm.n_layer % 2 == 0 &&
+           c->dm.d_model == kRD && c->hd == kRHD && c->dm.n_head == 4 && c->dm.n_layer % 2 == 0 &&
            c->n_cu >= kPG;
 }
 
@@ -765,11 +767,16 @@ static int rows_persist_prepare(gvc_gpt* c) {
     c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
                kCtlWords * sizeof(unsigned);
     int per_cu = 0;
-    if (hipFuncSetAttribute((const void*)k_rows_persist<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_rows_persist<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rows_persist<16>, kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rows_persist<8>, kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
-        hipMalloc((void**)&c->r_wpack, (size_t)L * kPG * kRWgLayerBytes) != hipSuccess ||
+    const void* kern[2] = {nullptr, nullptr};      // the two instantiations (8 / 16 padded rows) of this context's storage types
+    if (c->kv_bf16) { kern[0] = (const void*)k_rows_persist<8, 1, 1>; kern[1] = (const void*)k_rows_persist<16, 1, 1>; }
+    else if (c->bf16) { kern[0] = (const void*)k_rows_persist<8, 1, 0>; kern[1] = (const void*)k_rows_persist<16, 1, 0>; }
+    else { kern[0] = (const void*)k_rows_persist<8, 0, 0>; kern[1] = (const void*)k_rows_persist<16, 0, 0>; }
+    const int wsh = c->bf16 ? 1 : 0;
+    if (hipFuncSetAttribute(kern[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
+        hipFuncSetAttribute(kern[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern[1], kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern[0], kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
+        hipMalloc((void**)&c->r_wpack, (size_t)L * kPG * (kRWgLayerBytes >> wsh)) != hipSuccess ||
         hipMalloc((void**)&c->r_bufs, rows_buf_bytes()) != hipSuccess ||
         hipMalloc((void**)&c->r_layers, L * sizeof(RowsLayer)) != hipSuccess) {
         rows_persist_release(c);
@@ -781,9 +788,11 @@ static int rows_persist_prepare(gvc_gpt* c) {
         RowsLayer& p = t[l];
         p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_b = ly.qkv_b; p.proj_b = ly.proj_b; p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b;
         p.fc_b = ly.fc_b; p.p2_b = ly.p2_b; p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
-        hipLaunchKernelGGL(k_pack_rows_weights, dim3(2048), dim3(256), 0, 0,
-                           reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * kRWgLayerBytes),
-                           (const float*)ly.qkv_w, (const float*)ly.proj_w, (const float*)ly.fc_w, (const float*)ly.p2_w);
+        float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * (kRWgLayerBytes >> wsh));
+        if (wsh) hipLaunchKernelGGL(k_pack_rows_weights<1>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
+                                    (const float*)ly.fc_w, (const float*)ly.p2_w);
+        else hipLaunchKernelGGL(k_pack_rows_weights<0>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
+                                (const float*)ly.fc_w, (const float*)ly.p2_w);
     }
     if (hipGetLastError() != hipSuccess || hipMemcpy(c->r_layers, t.data(), L * sizeof(RowsLayer), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->r_bufs, 0xff, rows_buf_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -807,8 +816,16 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
     A.poll_all = poll_all;
     A.split1 = c->r_split1; A.split2 = c->r_split2;
-    if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8>), dim3(persist_test_grid()), dim3(kPThreads), c->r_lds, s, A);
-    else hipLaunchKernelGGL((k_rows_persist<16>), dim3(persist_test_grid()), dim3(kPThreads), c->r_lds, s, A);
+    const dim3 grid(persist_test_grid()), block(kPThreads);
+#define GVC_ROWS_LAUNCH(WBv, KVBv)                                                                        \
+    do {                                                                                                  \
+        if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8, WBv, KVBv>), grid, block, c->r_lds, s, A);   \
+        else hipLaunchKernelGGL((k_rows_persist<16, WBv, KVBv>), grid, block, c->r_lds, s, A);            \
+    } while (0)
+    if (c->kv_bf16) GVC_ROWS_LAUNCH(1, 1);
+    else if (c->bf16) GVC_ROWS_LAUNCH(1, 0);
+    else GVC_ROWS_LAUNCH(0, 0);
+#undef GVC_ROWS_LAUNCH
     GVC_LAUNCH_CHECK();
     c->r_launches += 1;
     return GVC_OK;

@@ -198,6 +198,11 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
     }
 }
 
+__device__ __forceinline__ float bf16_round(float v) { return __uint_as_float((unsigned)f32_to_bf16(v) << 16); }
+__device__ __forceinline__ float4 bf16x4_to_f4(pu32x2 h) {
+    return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+}
+
 template <int VN>
 __device__ __forceinline__ void vec_from_lds(const float* src, int lane, float4 (&v)[VN]) {
 #pragma unroll
@@ -206,15 +211,18 @@ __device__ __forceinline__ void vec_from_lds(const float* src, int lane, float4 
 
 // per-lane partial dot product of VN KiB of one weight row (in the ring from byte `off` of the segment whose first fill is
 // s0; the caller has waited for the fills) with vec
-template <int VN>
+// (offsets are written in fp32 bytes throughout; WB = 1: the ring holds bf16 rows at half of every offset, widened here)
+template <int VN, int WB = 0>
 __device__ __forceinline__ float row_partial(const char* ring, unsigned rmask, unsigned s0, unsigned off, int lane,
                                              const float4 (&vec)[VN]) {
     float sx = 0.f, sy = 0.f, sz = 0.f, sw = 0.f;
 #pragma unroll
     for (int j = 0; j < VN; ++j) {
-        const unsigned o = off + j * 1024u;
+        const unsigned o = (off + j * 1024u) >> WB;
         const unsigned slot = (s0 + (o >> 14)) & rmask;
-        const float4 w = *reinterpret_cast<const float4*>(ring + slot * kPSlot + (o & 16383u) + lane * 16);
+        float4 w;
+        if (WB) w = bf16x4_to_f4(*reinterpret_cast<const pu32x2*>(ring + slot * kPSlot + (o & 16383u) + lane * 8));
+        else w = *reinterpret_cast<const float4*>(ring + slot * kPSlot + (o & 16383u) + lane * 16);
         sx = fmaf(w.x, vec[j].x, sx); sy = fmaf(w.y, vec[j].y, sy);
         sz = fmaf(w.z, vec[j].z, sz); sw = fmaf(w.w, vec[j].w, sw);
     }
@@ -306,7 +314,7 @@ __device__ __forceinline__ float4 merge_chunks(PCtx& c, __amdgpu_buffer_rsrc_t g
 }
 
 // ---- loader wave: the workgroup's weight rows, phase after phase, into the ring ---------------------------------
-template <int ND>
+template <int ND, int WB>
 __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, char* ring) {
     constexpr unsigned D = 256 * ND;
     const unsigned rmask = A.ring_slots - 1;
@@ -317,24 +325,29 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
 #pragma unroll 1
     for (int sgi = 0; sgi < n_seg; ++sgi) {
         // segment = this workgroup's rows of one matrix: contiguous in the row-per-output layout
-        const float* base;
+        // WB = 1: the matrices are bf16 (2 bytes per element, PersistLayer pointers then address the bf16 copies)
+        const char* base;
         unsigned bytes;
         unsigned kib_stride = 1024;                  // global bytes between consecutive KiB of the segment (contiguous rows)
+        unsigned lane_off = c.lane * 16;             // this lane's 16 bytes inside a KiB of the segment
+        auto wptr = [&](const float* w, size_t elems) { return reinterpret_cast<const char*>(w) + ((elems * 4) >> WB); };
         if (sgi < 4 * A.n_layer) {
             const PersistLayer& Ly = A.layers[sgi >> 2];
             const int ph = sgi & 3;
-            if (ph == 0) { base = Ly.qkv_w + (size_t)c.wg * (3 * ND) * D; bytes = 3 * ND * D * 4; }
-            else if (ph == 1 && fused) {             // rows [i RF, (i+1) RF) x the 1 KiB K-slice of head h: one KiB per row
+            if (ph == 0) { base = wptr(Ly.qkv_w, (size_t)c.wg * (3 * ND) * D); bytes = (3 * ND * D * 4) >> WB; }
+            else if (ph == 1 && fused) {             // rows [i RF, (i+1) RF) x the 256-element K-slice of head h
                 const int h = c.wg % A.n_head, i = c.wg / A.n_head, RF = ND * A.n_head;
-                base = Ly.proj_w + (size_t)i * RF * D + h * 256; bytes = RF * 1024; kib_stride = D * 4;
+                base = wptr(Ly.proj_w, (size_t)i * RF * D + h * 256); bytes = (RF * 1024) >> WB; kib_stride = D * 4;
+                // fp32: one KiB per row; bf16: a KiB of the segment is TWO rows' 512-byte slices (lanes 32.. take the second)
+                if (WB) lane_off = (c.lane >> 5) * (D * 2) + (c.lane & 31) * 16;
             }
-            else if (ph == 1) { base = Ly.proj_w + (size_t)c.wg * ND * D; bytes = ND * D * 4; }
-            else if (ph == 2) { base = Ly.fc_w + (size_t)c.wg * (4 * ND) * D; bytes = 4 * ND * D * 4; }
-            else { base = Ly.p2_w + (size_t)c.wg * ND * (4 * D); bytes = ND * 4 * D * 4; }
+            else if (ph == 1) { base = wptr(Ly.proj_w, (size_t)c.wg * ND * D); bytes = (ND * D * 4) >> WB; }
+            else if (ph == 2) { base = wptr(Ly.fc_w, (size_t)c.wg * (4 * ND) * D); bytes = (4 * ND * D * 4) >> WB; }
+            else { base = wptr(Ly.p2_w, (size_t)c.wg * ND * (4 * D)); bytes = (ND * 4 * D * 4) >> WB; }
         } else if (sgi == 4 * A.n_layer) {
-            base = A.head_w + (size_t)c.wg * rm * D; bytes = rm * D * 4;
+            base = wptr(A.head_w, (size_t)c.wg * rm * D); bytes = (rm * D * 4) >> WB;
         } else {
-            base = A.head_w + (size_t)(rm * kPG + c.wg) * D; bytes = c.wg < rem ? D * 4 : 0;
+            base = wptr(A.head_w, (size_t)(rm * kPG + c.wg) * D); bytes = c.wg < rem ? (D * 4) >> WB : 0;
         }
 #pragma unroll 1
         for (unsigned off = 0; off < bytes; off += kPSlot) {
@@ -357,7 +370,7 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
             const unsigned n = (min((unsigned)kPSlot, bytes - off)) >> 10;
             const unsigned slot = __builtin_amdgcn_readfirstlane(fseq & rmask);
             char* dst = ring + slot * kPSlot;
-            const char* src = reinterpret_cast<const char*>(base) + (size_t)(off >> 10) * kib_stride + c.lane * 16;
+            const char* src = base + (size_t)(off >> 10) * kib_stride + lane_off;
             if (n == 16) {           // thinned: at most this fill and the one before it in flight
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -381,7 +394,7 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
 }
 
 // ---- decode-step kernel --------------------------------------------------------------------------------------
-template <int ND>      // d_model = 256 * ND
+template <int ND, int WB = 0, int KVB = 0>      // d_model = 256 * ND; bf16 weight storage; bf16 KV cache
 __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs A) {
     constexpr int D = 256 * ND;
     constexpr int KSC = ND % 2 == 0 ? 2 : 1;     // K-split of an attn c_proj row over waves (partial sums = planes of X0)
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
     const unsigned epoch = __hip_atomic_load(A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (c.wave == kPCW) {
-        persist_loader<ND>(A, c, ring);
+        persist_loader<ND, WB>(A, c, ring);
     } else {
         // `lane` is re-defined through an empty asm at every phase: without it the compiler hoists the per-lane addresses of all
         // phases out of the layer loop and spills them to scratch (vector memory behind the loader's DMA queue)
@@ -439,8 +452,9 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             if (stamp0 && l == 2 && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
         };
         unsigned fs = 0;                                 // first fill of the current weight segment
-        constexpr unsigned nfA = (3 * ND * D * 4 + kPSlot - 1) / kPSlot, nfC = (ND * D * 4 + kPSlot - 1) / kPSlot,
-                           nfD = (4 * ND * D * 4 + kPSlot - 1) / kPSlot;
+        constexpr unsigned nfA = (((3 * ND * D * 4) >> WB) + kPSlot - 1) / kPSlot, nfC = (((ND * D * 4) >> WB) + kPSlot - 1) / kPSlot,
+                           nfD = (((4 * ND * D * 4) >> WB) + kPSlot - 1) / kPSlot;
+        constexpr int FSH = 14 + WB;                 // fill index of a byte offset written in fp32 bytes
         auto phase_done = [&]() { if (lane == 0) lds_st(ctl + kCtlDone + wave, fs); };
 
         // ---- x = mel_embedding[tok] + mel_pos_embedding[pos]  (gpt_inference.py:92-96), by every workgroup ----
@@ -472,11 +486,11 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     vec_from_lds<ND>(xvec, lane, xv);
                     layer_norm_regs<ND>(xv, g, b);
                     stamp_at(l, 0, 2);
-                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> 14));
+                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
 #pragma unroll
                     for (int i = 0; i < UPW; ++i)
-                        part[i] = i < nmy ? row_partial<ND>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
+                        part[i] = i < nmy ? row_partial<ND, WB>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
 #pragma unroll
                     for (int i = 0; i < UPW; ++i) {
                         const float s = wave_sum(part[i]);
@@ -486,12 +500,15 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 stamp_at(l, 0, 3);
                 if (lane < nmy) {
                     val += bias;
+                    if (KVB && row_g >= D) val = bf16_round(val);      // a bf16 cache: k / v rounded where they enter it, this step's attention reads the same values
                     publish(grs, iQ + row_g, tag_of(l, 0), val);
                     if (row_g >= D) {            // append k / v of this position to the cache (read by later steps)
                         const int which = row_g / D, ci = row_g - which * D;
                         const int h = ci / hd, j = ci - h * hd;
                         float* cache = which == 1 ? Ly.kcache : Ly.vcache;
-                        cache[(((size_t)slot * H + h) * A.max_seq + S) * hd + j] = val;
+                        const size_t e = (((size_t)slot * H + h) * A.max_seq + S) * hd + j;
+                        if (KVB) reinterpret_cast<unsigned short*>(cache)[e] = (unsigned short)(__float_as_uint(val) >> 16);
+                        else cache[e] = val;
                     }
                 }
                 fs += nfA;
@@ -504,24 +521,35 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int kl = lane / lpk, dl = (lane - kl * lpk) * 4;
                 const int k0 = ac * kc, k1 = min(S, k0 + kc);            // cached keys of this chunk
                 // this head's rows of the layer's K / V cache as buffers: one per-lane offset serves every key of a pass
-                const unsigned head_bytes = (unsigned)A.max_seq * hd * 4u;
-                const __amdgpu_buffer_rsrc_t krs = make_rsrc(Ly.kcache + ((size_t)slot * H + ah) * A.max_seq * hd, head_bytes);
-                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(Ly.vcache + ((size_t)slot * H + ah) * A.max_seq * hd, head_bytes);
-                const int kv_step = kPCW * kpw * hd * 4;                     // bytes between the keys u and u + 1 of a lane
+                constexpr int ESZ = KVB ? 2 : 4;                             // bytes per cache element
+                const unsigned head_bytes = (unsigned)A.max_seq * hd * ESZ;
+                const size_t head_off = ((size_t)slot * H + ah) * A.max_seq * hd * ESZ;
+                const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Ly.kcache) + head_off, head_bytes);
+                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Ly.vcache) + head_off, head_bytes);
+                const int kv_step = kPCW * kpw * hd * ESZ;                   // bytes between the keys u and u + 1 of a lane
                 float4 kr[kPU], vr[kPU];
                 auto load_pass = [&](int kbase) {
                     const int key0 = kbase + wave * kpw + kl;
-                    const int voff = (key0 * hd + dl) * 4;
+                    const int voff = (key0 * hd + dl) * ESZ;
 #pragma unroll
                     for (int u = 0; u < kPU; ++u) {
                         const bool ok = key0 + u * kPCW * kpw < k1;
-                        pu32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                        if (ok) {
-                            kk = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kv_step, 0);
-                            vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kv_step, 0);
+                        if (KVB) {
+                            pu32x2 kk = {0u, 0u}, vv = {0u, 0u};
+                            if (ok) {
+                                kk = __builtin_amdgcn_raw_buffer_load_b64(krs, voff, u * kv_step, 0);
+                                vv = __builtin_amdgcn_raw_buffer_load_b64(vrs, voff, u * kv_step, 0);
+                            }
+                            kr[u] = bf16x4_to_f4(kk); vr[u] = bf16x4_to_f4(vv);
+                        } else {
+                            pu32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                            if (ok) {
+                                kk = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kv_step, 0);
+                                vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kv_step, 0);
+                            }
+                            kr[u] = make_float4(__uint_as_float(kk.x), __uint_as_float(kk.y), __uint_as_float(kk.z), __uint_as_float(kk.w));
+                            vr[u] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
                         }
-                        kr[u] = make_float4(__uint_as_float(kk.x), __uint_as_float(kk.y), __uint_as_float(kk.z), __uint_as_float(kk.w));
-                        vr[u] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
                     }
                 };
                 load_pass(k0);          // requested ahead of the seam: these rows were written by earlier launches
@@ -625,21 +653,32 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             if (fused) {
                 GVC_PHASE_BEGIN();
                 const int fh = wg % H, fi = wg / H, RF = ND * H;        // head, row block, rows of the block
-                const unsigned head_bytes = (unsigned)A.max_seq * 256u * 4u;
-                const __amdgpu_buffer_rsrc_t krs = make_rsrc(Ly.kcache + ((size_t)slot * H + fh) * A.max_seq * 256, head_bytes);
-                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(Ly.vcache + ((size_t)slot * H + fh) * A.max_seq * 256, head_bytes);
+                constexpr int ESZ = KVB ? 2 : 4;
+                const unsigned head_bytes = (unsigned)A.max_seq * 256u * ESZ;
+                const size_t head_off = ((size_t)slot * H + fh) * A.max_seq * 256 * ESZ;
+                const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Ly.kcache) + head_off, head_bytes);
+                const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Ly.vcache) + head_off, head_bytes);
                 float4 kr[kPUF], vr[kPUF];
                 {       // cached rows of the whole head (written by earlier launches), requested ahead of the seam: key u * 8 + wave
-                    const int voff = (wave * 256 + lane * 4) * 4;
+                    const int voff = (wave * 256 + lane * 4) * ESZ;
 #pragma unroll
                     for (int u = 0; u < kPUF; ++u) {
-                        pu32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-                        if (u * kPCW + wave < S) {
-                            kk = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * 1024, 0);
-                            vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * 1024, 0);
+                        if (KVB) {
+                            pu32x2 kk = {0u, 0u}, vv = {0u, 0u};
+                            if (u * kPCW + wave < S) {
+                                kk = __builtin_amdgcn_raw_buffer_load_b64(krs, voff, u * kPCW * 256 * ESZ, 0);
+                                vv = __builtin_amdgcn_raw_buffer_load_b64(vrs, voff, u * kPCW * 256 * ESZ, 0);
+                            }
+                            kr[u] = bf16x4_to_f4(kk); vr[u] = bf16x4_to_f4(vv);
+                        } else {
+                            pu32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+                            if (u * kPCW + wave < S) {
+                                kk = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * 256 * ESZ, 0);
+                                vv = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * 256 * ESZ, 0);
+                            }
+                            kr[u] = make_float4(__uint_as_float(kk.x), __uint_as_float(kk.y), __uint_as_float(kk.z), __uint_as_float(kk.w));
+                            vr[u] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
                         }
-                        kr[u] = make_float4(__uint_as_float(kk.x), __uint_as_float(kk.y), __uint_as_float(kk.z), __uint_as_float(kk.w));
-                        vr[u] = make_float4(__uint_as_float(vv.x), __uint_as_float(vv.y), __uint_as_float(vv.z), __uint_as_float(vv.w));
                     }
                 }
                 const int r0 = wave, r1 = wave + kPCW;                   // this wave's rows of the block (RF <= 16)
@@ -717,9 +756,9 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 oh[0].x *= inv; oh[0].y *= inv; oh[0].z *= inv; oh[0].w *= inv;
                 stamp_at(l, 2, 0);
                 if (r0 < RF) {
-                    wait_fill(c, fs + ((unsigned)(r1 < RF ? r1 : r0) * 1024u + 1023u >> 14));
-                    const float p0 = row_partial<1>(ring, rmask, fs, (unsigned)r0 * 1024u, lane, oh);
-                    const float p1 = r1 < RF ? row_partial<1>(ring, rmask, fs, (unsigned)r1 * 1024u, lane, oh) : 0.f;
+                    wait_fill(c, fs + (((unsigned)(r1 < RF ? r1 : r0) * 1024u + 1023u) >> FSH));
+                    const float p0 = row_partial<1, WB>(ring, rmask, fs, (unsigned)r0 * 1024u, lane, oh);
+                    const float p1 = r1 < RF ? row_partial<1, WB>(ring, rmask, fs, (unsigned)r1 * 1024u, lane, oh) : 0.f;
                     float s0 = wave_sum(p0), s1 = wave_sum(p1);
                     if (fh == 0) {                                       // plane 0 carries the residual (x of this layer is still in xvec) and the bias
                         s0 = xvec[fi * RF + r0] + (s0 + bias0);
@@ -754,8 +793,8 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     float4 ov[VN];
                     vec_from_lds<VN>(ovec + cks * VN * 256, lane, ov);
                     const unsigned off = (unsigned)crow * D * 4 + (unsigned)cks * VN * 1024u;
-                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> 14));
-                    float s = wave_sum(row_partial<VN>(ring, rmask, fs, off, lane, ov));
+                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> FSH));
+                    float s = wave_sum(row_partial<VN, WB>(ring, rmask, fs, off, lane, ov));
                     if (cks == 0) s = xvec[wg * ND + crow] + (s + bias);       // residual: x of this layer (A's input) is still in xvec
                     if (lane == 0) publish(grs, iX0 + cks * D + wg * ND + crow, tag_of(l, 2), s);
                 }
@@ -782,11 +821,11 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 if (nmy > 0) {
                     vec_from_lds<ND>(xvec, lane, xv);
                     layer_norm_regs<ND>(xv, g, b);
-                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> 14));
+                    wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
 #pragma unroll
                     for (int i = 0; i < UPW; ++i)
-                        part[i] = i < nmy ? row_partial<ND>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
+                        part[i] = i < nmy ? row_partial<ND, WB>(ring, rmask, fs, (unsigned)(wave + kPCW * i) * D * 4, lane, xv) : 0.f;
 #pragma unroll
                     for (int i = 0; i < UPW; ++i) {
                         const float s = wave_sum(part[i]);
@@ -812,8 +851,8 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     float4 hv[VN];
                     vec_from_lds<VN>(hvec + eks * VN * 256, lane, hv);
                     const unsigned off = (unsigned)erow * 4 * D * 4 + (unsigned)eks * VN * 1024u;
-                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> 14));
-                    float s = wave_sum(row_partial<VN>(ring, rmask, fs, off, lane, hv));
+                    wait_fill(c, fs + ((off + VN * 1024u - 1u) >> FSH));
+                    float s = wave_sum(row_partial<VN, WB>(ring, rmask, fs, off, lane, hv));
                     if (eks == 0) s = xvec[wg * ND + erow] + (s + bias);       // residual: x' (D's input) is still in xvec
                     if (lane == 0) publish(grs, iX1 + eks * D + wg * ND + erow, tag_of(l, 4), s);
                 }
@@ -848,18 +887,18 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             float val = 0.f;
             for (int i = 0; i < nmy; ++i) {
                 const unsigned off = (unsigned)(wave + kPCW * i) * D * 4;
-                wait_fill(c, fs + ((off + D * 4 - 1) >> 14));
-                const float s = wave_sum(row_partial<ND>(ring, rmask, fs, off, lane, xv));
+                wait_fill(c, fs + ((off + D * 4 - 1) >> FSH));
+                const float s = wave_sum(row_partial<ND, WB>(ring, rmask, fs, off, lane, xv));
                 if (lane == i) val = s;
             }
             if (lane < nmy) A.logits_out[row_g] = val + bias;
-            if (rm > 0) fs += (rm * D * 4 + kPSlot - 1) / kPSlot;
+            if (rm > 0) fs += (((rm * D * 4) >> WB) + kPSlot - 1) / kPSlot;
             if (tail) {
                 wait_fill(c, fs);
-                const float s = wave_sum(row_partial<ND>(ring, rmask, fs, 0u, lane, xv));
+                const float s = wave_sum(row_partial<ND, WB>(ring, rmask, fs, 0u, lane, xv));
                 if (lane == 0) A.logits_out[rm * kPG + wg] = s + tbias;
             }
-            if (wg < rem) fs += (D * 4 + kPSlot - 1) / kPSlot;
+            if (wg < rem) fs += (((D * 4) >> WB) + kPSlot - 1) / kPSlot;
             phase_done();
             stamp_at(L, 0, 1);
             if (wg == 0 && wave == 0 && lane == 0) {

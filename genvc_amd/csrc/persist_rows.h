@@ -71,6 +71,7 @@ struct RowsArgs {
 };
 
 // packed weights: [layer][wg]{ A: 3 groups | C: 1 | D: 4 | E: 1 }, group = 4 rows x K as [K / 4][4 rows][4]
+template <int WB>      // WB = 1: bf16 elements (the fp32 sources of a bf16-weights context are already rounded: the upper halves are exact)
 __global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* proj, const float* fc, const float* p2) {
     const size_t n4 = (size_t)kPG * kRWgLayerBytes / 16;                 // float4 per layer
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -84,9 +85,26 @@ __global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* p
         else if (r < 8 * 1024) { r -= 4 * 1024; src = fc; K = kRD; row0 = wg * 16 + (r >> 10) * 4; r &= 1023; }
         else { r -= 8 * 1024; src = p2; K = 4 * kRD; row0 = wg * 4; }
         const int t = r & 3, q = r >> 2;
-        reinterpret_cast<float4*>(dst)[i] = *reinterpret_cast<const float4*>(src + (size_t)(row0 + t) * K + q * 4);
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + t) * K + q * 4);
+        if (WB) {
+            uint2 h;
+            h.x = (__float_as_uint(v.x) >> 16) | (__float_as_uint(v.y) & 0xffff0000u);
+            h.y = (__float_as_uint(v.z) >> 16) | (__float_as_uint(v.w) & 0xffff0000u);
+            reinterpret_cast<uint2*>(dst)[i] = h;
+        } else reinterpret_cast<float4*>(dst)[i] = v;
     }
 }
+
+// four consecutive weights of one row from the ring: 16 bytes of fp32, or 8 bytes of bf16 widened in registers
+template <int WB>
+__device__ __forceinline__ float4 ldw4(const char* p) {
+    if (WB) {
+        const uint2 h = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
 
 __device__ __forceinline__ bool rclean(pu32x4 v) { return v.x != kRPoison && v.y != kRPoison && v.z != kRPoison && v.w != kRPoison; }
 __device__ __forceinline__ float4 as_f4(pu32x4 v) {
@@ -158,13 +176,16 @@ __device__ __forceinline__ float kk_sum(float v) {
 }
 
 // ---- loader wave -------------------------------------------------------------------------------------------------
+// a fill = one 4-row group over 1024 inputs = one ring slot: 16 KiB of fp32 or (WB) 8 KiB of bf16 in the slot's first half
+template <int WB>
 __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ring) {
+    constexpr int NP = 16 >> WB;                     // 1 KiB LDS-DMA instructions per fill
     const unsigned rmask = A.ring_slots - 1;
     unsigned fseq = 0;
-    const char* base = A.wpack + (size_t)c.wg * kRWgLayerBytes + c.lane * 16;
+    const char* base = A.wpack + (size_t)c.wg * (kRWgLayerBytes >> WB) + c.lane * 16;
 #pragma unroll 1
     for (int l = 0; l < A.n_layer; ++l) {
-        const char* lsrc = base + (size_t)l * kPG * kRWgLayerBytes;
+        const char* lsrc = base + (size_t)l * kPG * (kRWgLayerBytes >> WB);
 #pragma unroll 1
         for (int f = 0; f < kRWgLayerBytes / kPSlot; ++f) {
             unsigned spins = 0;
@@ -183,12 +204,13 @@ __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ri
             }
             if (c.dead) return;
             char* dst = ring + (size_t)__builtin_amdgcn_readfirstlane(fseq & rmask) * kPSlot;
-            const char* src = lsrc + (size_t)f * kPSlot;
+            const char* src = lsrc + (size_t)f * (kPSlot >> WB);
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (WB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             lds_st(c.ctl + kCtlFilled, fseq);
             ++fseq;
         }
@@ -198,7 +220,7 @@ __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ri
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-template <int R>       // padded row count: 8 or 16
+template <int R, int WB, int KVB>       // padded row count (8 or 16); bf16 weight storage; bf16 KV cache
 __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     constexpr int D = kRD, HD = kRHD;
     constexpr int G = R / 4, KK = 16 / G;            // row groups, k positions (quads) per MFMA step
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.wg = blockIdx.x;
     c.ctl = ctl; c.err = A.err; c.bar_target = 0; c.filled_seen = 0; c.dead = false;
     if (c.wave == kPCW) {
-        rows_loader(A, c, ring);
+        rows_loader<WB>(A, c, ring);
         return;
     }
     int& lane = c.lane;
@@ -331,17 +353,17 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             {
                 // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
                 // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
-                const char* wbase = ring + (s0 * STEPB + (lane & LMASK) * 16);
+                const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
                 const float* gb = gbs + (wave * 64 + kk) * 4;
                 float4 wc[3], wn[3], gc, bc, gn, bn;
 #pragma unroll
-                for (int rg = 0; rg < 3; ++rg) wc[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+                for (int rg = 0; rg < 3; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
                 gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
                     if (i + 1 < NSX) {
 #pragma unroll
-                        for (int rg = 0; rg < 3; ++rg) wn[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (i + 1) * STEPB);
+                        for (int rg = 0; rg < 3; ++rg) wn[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (((i + 1) * STEPB) >> WB));
                         gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
                     }
                     const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
@@ -381,6 +403,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 const int col = wg * 12 + rg * 4;
                 const float4 bi = bpre;
                 s.x += bi.x; s.y += bi.y; s.z += bi.z; s.w += bi.w;
+                if (KVB && col >= D) {                        // a bf16 cache: k and v are rounded where they enter it, and this step's
+                    s.x = bf16_round(s.x); s.y = bf16_round(s.y); s.z = bf16_round(s.z); s.w = bf16_round(s.w);      // attention reads the same values
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's poison of the previous layer has landed
                 const int eo = (kRoffQKV + rn * 3 * D + col) * 4;
                 rpublish(brs, pc + eo, po + eo, s);
@@ -390,7 +415,13 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     const int pos = (A.base_len ? A.base_len[slot] : 0) + t;
                     if (pos < A.max_seq) {
                         float* cache = which == 1 ? Lp->kcache : Lp->vcache;
-                        *reinterpret_cast<float4*>(cache + (((size_t)slot * H + h) * A.max_seq + pos) * HD + j) = s;
+                        const size_t e = (((size_t)slot * H + h) * A.max_seq + pos) * HD + j;
+                        if (KVB) {
+                            uint2 hv;
+                            hv.x = (__float_as_uint(s.x) >> 16) | (__float_as_uint(s.y) & 0xffff0000u);
+                            hv.y = (__float_as_uint(s.z) >> 16) | (__float_as_uint(s.w) & 0xffff0000u);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(cache) + e) = hv;
+                        } else *reinterpret_cast<float4*>(cache + e) = s;
                     } else *A.err = 950;                      // KV cache full: GVC_ERR_STATE on the host's next call
                 }
             }
@@ -406,21 +437,33 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int base = A.base_len ? A.base_len[slot] : 0;
             const int k0 = active ? (int)(((long long)base * ch) / nch) : 0, k1 = active ? (int)(((long long)base * (ch + 1)) / nch) : 0;
             const bool last = active && ch == nch - 1;           // the new rows [r0, n] of this very step belong to the last chunk
-            const unsigned head_bytes = (unsigned)A.max_seq * HD * 4u;
-            const __amdgpu_buffer_rsrc_t krs = make_rsrc(Lp->kcache + ((size_t)slot * H + h) * A.max_seq * HD, head_bytes);
-            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(Lp->vcache + ((size_t)slot * H + h) * A.max_seq * HD, head_bytes);
+            constexpr int ESZ = KVB ? 2 : 4;                     // bytes per cache element
+            const unsigned head_bytes = (unsigned)A.max_seq * HD * ESZ;
+            const size_t head_off = ((size_t)slot * H + h) * A.max_seq * HD * ESZ;
+            const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Lp->kcache) + head_off, head_bytes);
+            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Lp->vcache) + head_off, head_bytes);
             constexpr int U = 8;                                 // keys per wave and pass: 64 keys of the chunk per pass
             float4 kr[U], vr[U];
             auto load_pass = [&](int kb) {                       // keys kb + wave + 8 u of the cache (written by earlier launches)
-                const int voff = ((kb + wave) * HD + lane * 4) * 4;
+                const int voff = ((kb + wave) * HD + lane * 4) * ESZ;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    pu32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
-                    if (kb + wave + u * kPCW < k1) {
-                        kq = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * HD * 4, 0);
-                        vq = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * HD * 4, 0);
+                    if (KVB) {                                   // 8 bytes = 4 bf16 per lane, widened at use
+                        pu32x2 kq = {0u, 0u}, vq = {0u, 0u};
+                        if (kb + wave + u * kPCW < k1) {
+                            kq = __builtin_amdgcn_raw_buffer_load_b64(krs, voff, u * kPCW * HD * ESZ, 0);
+                            vq = __builtin_amdgcn_raw_buffer_load_b64(vrs, voff, u * kPCW * HD * ESZ, 0);
+                        }
+                        kr[u] = make_float4(__uint_as_float(kq.x << 16), __uint_as_float(kq.x & 0xffff0000u), __uint_as_float(kq.y << 16), __uint_as_float(kq.y & 0xffff0000u));
+                        vr[u] = make_float4(__uint_as_float(vq.x << 16), __uint_as_float(vq.x & 0xffff0000u), __uint_as_float(vq.y << 16), __uint_as_float(vq.y & 0xffff0000u));
+                    } else {
+                        pu32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
+                        if (kb + wave + u * kPCW < k1) {
+                            kq = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * HD * ESZ, 0);
+                            vq = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * HD * ESZ, 0);
+                        }
+                        kr[u] = as_f4(kq); vr[u] = as_f4(vq);
                     }
-                    kr[u] = as_f4(kq); vr[u] = as_f4(vq);
                 }
             };
             load_pass(k0);                                       // requested ahead of the seam
@@ -596,11 +639,11 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             wait_fill(c, fs);
             {
-                const char* wbase = ring + (size_t)(fs & rmask) * kPSlot + (s0 * STEPB + (lane & LMASK) * 16);
-                float4 wc = *reinterpret_cast<const float4*>(wbase), wn;
+                const char* wbase = ring + (size_t)(fs & rmask) * kPSlot + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
+                float4 wc = ldw4<WB>(wbase), wn;
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
-                    if (i + 1 < NSX) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
+                    if (i + 1 < NSX) wn = ldw4<WB>(wbase + (((i + 1) * STEPB) >> WB));
                     acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, ov[i].x, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, ov[i].y, acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.z, ov[i].z, acc0, 0, 0, 0);
@@ -691,17 +734,17 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             {
                 // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
                 // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
-                const char* wbase = ring + (s0 * STEPB + (lane & LMASK) * 16);
+                const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
                 const float* gb = gbs + (wave * 64 + kk) * 4;
                 float4 wc[4], wn[4], gc, bc, gn, bn;
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) wc[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+                for (int rg = 0; rg < 4; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
                 gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
                     if (i + 1 < NSX) {
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) wn[rg] = *reinterpret_cast<const float4*>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (i + 1) * STEPB);
+                        for (int rg = 0; rg < 4; ++rg) wn[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (((i + 1) * STEPB) >> WB));
                         gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
                     }
                     const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
@@ -792,11 +835,11 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 wait_fill(c, fs + ((boff + 16 * STEPB - 1) >> 14));
                 {
                     // (a chunk of 16 steps lies inside one 16 KiB ring slot: 16 steps x 256 / 512 bytes <= 8 KiB)
-                    const char* wbase = ring + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot + ((boff & 16383u) + (lane & LMASK) * 16);
-                    float4 wc = *reinterpret_cast<const float4*>(wbase), wn;
+                    const char* wbase = ring + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot + (((boff & 16383u) + (lane & LMASK) * 16) >> WB);
+                    float4 wc = ldw4<WB>(wbase), wn;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        if (i + 1 < 16) wn = *reinterpret_cast<const float4*>(wbase + (i + 1) * STEPB);
+                        if (i + 1 < 16) wn = ldw4<WB>(wbase + (((i + 1) * STEPB) >> WB));
                         const float4 hv = as_f4(raw[ck][i]);
                         acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, hv.x, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, hv.y, acc1, 0, 0, 0);
