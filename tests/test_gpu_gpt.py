@@ -533,8 +533,8 @@ def test_config4_batched_prefill_agrees_with_single_segments():
         np.testing.assert_allclose(lats_1[0].numpy(), lats_b[b].numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("d,H,L", [(1024, 16, 3), (512, 4, 3), (768, 12, 2), (768, 3, 2), (512, 8, 2)],
-                         ids=["d1024_h16_hd64", "d512_h4_hd128", "d768_h12_hd64", "d768_h3_hd256", "d512_h8_hd64"])
+@pytest.mark.parametrize("d,H,L", [(1024, 16, 4), (512, 4, 4), (768, 12, 2), (768, 3, 2), (512, 8, 2), (512, 4, 3)],
+                         ids=["d1024_h16_hd64", "d512_h4_hd128", "d768_h12_hd64", "d768_h3_hd256", "d512_h8_hd64", "odd_layer_count"])
 @pytest.mark.parametrize("persist", ["1", "0"], ids=["one_launch_step", "launch_per_phase"])
 def test_other_model_dims_vs_oracle(d, H, L, persist, monkeypatch):
     """the real checkpoints' dims live in their config (inference/model_init.py:11-12; configs/genVC_configs.py:132 defaults to 16
