@@ -764,7 +764,7 @@ static void rows_persist_release(gvc_gpt* c) {
 static int rows_persist_prepare(gvc_gpt* c) {
     if (c->r_ready != 0) return GVC_OK;
     const int L = c->dm.n_layer;
-    c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
+    c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + 3 * kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
                kCtlWords * sizeof(unsigned);
     int per_cu = 0;
     const void* kern[2] = {nullptr, nullptr};      // the two instantiations (8 / 16 padded rows) of this context's storage types
@@ -807,12 +807,14 @@ static int rows_persist_prepare(gvc_gpt* c) {
     return GVC_OK;
 }
 
-static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T, const int32_t* base_len, int nch, hipStream_t s) {
+static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T, const int32_t* base_len, int nch, hipStream_t s,
+                               const int32_t* tok_in = nullptr) {
     RowsArgs A;
     memset(&A, 0, sizeof(A));
     A.layers = c->r_layers; A.wpack = reinterpret_cast<const char*>(c->r_wpack); A.n_layer = c->dm.n_layer; A.n_head = c->dm.n_head;
     A.max_seq = c->dm.max_seq; A.rows = rows; A.T = T; A.slots = slots; A.base_len = base_len; A.x = c->x; A.bufs = c->r_bufs;
     A.err = c->seam_err_dev; A.ring_slots = 8; A.nchunks = nch; A.dbg = c->r_dbg;
+    A.tok_in = tok_in; A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.mel_pos_idx = c->st.mel_pos; A.vocab = c->dm.vocab;
     static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
     A.poll_all = poll_all;
     A.split1 = c->r_split1; A.split2 = c->r_split2;
@@ -908,9 +910,13 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
                        int32_t* step_ctr, hipStream_t s, int key_chunks = 1) {
     const int d = c->dm.d_model;
     int rc;
-    hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d, c->dm.vocab);
-    GVC_LAUNCH_CHECK();
-    if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len, key_chunks))) return rc;
+    if (c->r_ready == 1 && rows_persist_ok(c, B, c->st.seq_len)) {        // the one-launch rows step builds its input rows itself
+        if ((rc = launch_rows_persist(c, slots, B, 1, c->st.seq_len, rows_persist_chunks(c, B, c->rows_keys_hint), s, tok_in))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_embed_decode_rows, dim3(B), dim3(256), 0, s, c->x, tok_in, slots, c->st, c->mel_emb, c->mel_pos, d, c->dm.vocab);
+        GVC_LAUNCH_CHECK();
+        if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len, key_chunks))) return rc;
+    }
     for (int g = 0; g < B; g += 8) {
         const int Bg = B - g < 8 ? B - g : 8;
         GemvArgs A = base_args(c, slots + g, g);
@@ -1218,10 +1224,13 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
 // ---------------------------------------------------------------------------------------------
 // generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
 // ---------------------------------------------------------------------------------------------
-static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, hipGraphExec_t* out) {
+static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, int n_unroll, hipGraphExec_t* out) {
     hipStream_t cs = c->cap_stream;
     int rc = GVC_OK;
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    // n_unroll consecutive steps in ONE graph: the boundary between two graph launches costs several times the boundary between
+    // two kernels of a graph, and the host looks at the finished flags once per group of steps anyway
+    for (int u = 0; u < n_unroll && rc == GVC_OK; ++u) {
     rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
     if (rc == GVC_OK && persist_ok(c, B))
         rc = launch_persist(c, c->gen_call->slots, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
@@ -1233,6 +1242,7 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, hipGr
         const bool last = g + 8 >= B;
         rc = decode_group(c, c->gen_call->slots + g, Bg, g, c->tok_buf + g, c->logits + (size_t)g * c->dm.vocab,
                           c->latent + (size_t)g * c->dm.d_model, last ? c->step_ctr : nullptr, cs, fused);
+    }
     }
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(cs, &graph);
@@ -1283,13 +1293,31 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     c->rows_keys_hint = key_bound;
     const int key = B * 2 + (fused ? 1 : 0) + 4096 * (rows1 ? 8 + rows_persist_chunks(c, B, key_bound) : key_chunks);   // (the one-launch steps are pure functions of B [and the key split])
     c->last_variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1)));
-    auto it = c->graphs.find(key);
-    if (it == c->graphs.end()) {
+    // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
+    static const int kStepUnroll = getenv("GVC_STEP_UNROLL") ? std::max(1, atoi(getenv("GVC_STEP_UNROLL"))) : 8;
+    auto graph_of = [&](int unroll, hipGraphExec_t* ge) -> int {
+        const int k = key + (unroll > 1 ? (1 << 24) * unroll : 0);
+        auto it = c->graphs.find(k);
+        if (it == c->graphs.end()) {
+            hipGraphExec_t g1;
+            int r = build_step_graph(c, B, fused, key_chunks, unroll, &g1);
+            if (r) return r;
+            it = c->graphs.emplace(k, g1).first;
+        }
+        *ge = it->second;
+        return GVC_OK;
+    };
+    int left = n_steps;
+    if (kStepUnroll > 1 && left >= kStepUnroll) {
         hipGraphExec_t ge;
-        if ((rc = build_step_graph(c, B, fused, key_chunks, &ge))) return rc;
-        it = c->graphs.emplace(key, ge).first;
+        if ((rc = graph_of(kStepUnroll, &ge))) return rc;
+        for (; left >= kStepUnroll; left -= kStepUnroll) GVC_CHECK_HIP(hipGraphLaunch(ge, s));
     }
-    for (int i = 0; i < n_steps; ++i) GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
+    if (left > 0) {
+        hipGraphExec_t ge;
+        if ((rc = graph_of(1, &ge))) return rc;
+        for (; left > 0; --left) GVC_CHECK_HIP(hipGraphLaunch(ge, s));
+    }
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
     hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 1);
     GVC_LAUNCH_CHECK();

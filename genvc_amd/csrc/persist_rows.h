@@ -44,7 +44,7 @@ constexpr int kRoffML = kRoffOP + kRMaxChunks * kRMaxRows * kRD;              //
 constexpr int kRoffX0 = kRoffML + kRMaxChunks * kRMaxRows * 4 * 4;
 constexpr int kRoffHH = kRoffX0 + kRMaxRows * kRD;
 constexpr int kRoffX1 = kRoffHH + kRMaxRows * 4 * kRD;
-constexpr int kRParFloats = kRoffX1 + kRMaxRows * kRD;
+constexpr int kRParFloats = kRoffX1 + 2 * kRMaxRows * kRD;        // X1: two K-half planes of the mlp c_proj (their sum is x)
 __host__ __device__ static inline size_t rows_buf_bytes() { return (size_t)2 * kRParFloats * sizeof(float); }
 
 typedef float pf32x4 __attribute__((ext_vector_type(4)));
@@ -61,7 +61,11 @@ struct RowsArgs {
     int rows, T;                    // active rows; rows [b T, (b + 1) T) continue stream b at base_len[slot b] + 0 .. T - 1
     const int32_t* slots;
     const int32_t* base_len;        // per slot; null: 0
-    float* x;                       // [rows][1024] row-major: block-stack input, overwritten with its output
+    float* x;                       // [rows][1024] row-major: block-stack input (unless tok_in), overwritten with its output
+    const int32_t* tok_in;          // decode steps: row n enters as mel_emb[tok_in[n]] + mel_pos[mel_pos_idx[slot n]] (gpt_inference.py:92-96); null: x
+    const float *mel_emb, *mel_pos;
+    const int32_t* mel_pos_idx;     // per slot
+    int vocab;
     float* bufs;                    // [2][kRParFloats]
     int* err;
     int ring_slots, nchunks;        // nchunks: upper bound of the key split (the kernel picks 1 / 2 / 4 from the longest context it finds)
@@ -70,7 +74,7 @@ struct RowsArgs {
     unsigned long long* dbg;
 };
 
-// packed weights: [layer][wg]{ A: 3 groups | C: 1 | D: 4 | E: 1 }, group = 4 rows x K as [K / 4][4 rows][4]
+// packed weights: [layer][wg]{ A: 3 groups | C: 1 | D: 4 | E: 2 half-K groups }, group = 4 rows x K as [K / 4][4 rows][4]
 template <int WB>      // WB = 1: bf16 elements (the fp32 sources of a bf16-weights context are already rounded: the upper halves are exact)
 __global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* proj, const float* fc, const float* p2) {
     const size_t n4 = (size_t)kPG * kRWgLayerBytes / 16;                 // float4 per layer
@@ -83,7 +87,9 @@ __global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* p
         if (r < 3 * 1024) { src = qkv; K = kRD; row0 = wg * 12 + (r >> 10) * 4; r &= 1023; }
         else if (r < 4 * 1024) { src = proj; K = kRD; row0 = wg * 4; r -= 3 * 1024; }
         else if (r < 8 * 1024) { r -= 4 * 1024; src = fc; K = kRD; row0 = wg * 16 + (r >> 10) * 4; r &= 1023; }
-        else { r -= 8 * 1024; src = p2; K = 4 * kRD; row0 = wg * 4; }
+        else {          // mlp c_proj: workgroup (cb, kh) = (wg / 2, wg % 2) owns columns [8 cb, 8 cb + 8) over K-half kh: two 4-row groups x 2048 inputs
+            r -= 8 * 1024; src = p2; K = 4 * kRD; row0 = (wg >> 1) * 8 + (r >> 11) * 4; r = (r & 2047) + (wg & 1) * 2048;
+        }
         const int t = r & 3, q = r >> 2;
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(row0 + t) * K + q * 4);
         if (WB) {
@@ -155,6 +161,32 @@ __device__ __forceinline__ void rgather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int 
 #pragma unroll
         for (int i = 1; i < NL; ++i) {
             if (__any(!rclean(v[i]))) { v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16); again = true; }
+        }
+        if (!again) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+}
+
+// two planes of NL pieces each (K-half partial sums, `poff` bytes apart): ONE sentinel piece is polled, then both planes are requested
+// together -- a second plane costs no second round trip
+template <int NL>
+__device__ __forceinline__ void rgather2(PCtx& c, __amdgpu_buffer_rsrc_t rs, int off, int stride, int poff, pu32x4 (&v)[NL], pu32x4 (&w)[NL], int code) {
+    unsigned spins = 0;
+    while (true) {
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        if (__all(rclean(v[0]))) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+#pragma unroll
+    for (int i = 1; i < NL; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + poff, i * stride, 16);
+    while (true) {
+        bool again = false;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (i > 0 && __any(!rclean(v[i]))) { v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, i * stride, 16); again = true; }
+            if (__any(!rclean(w[i]))) { w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + poff, i * stride, 16); again = true; }
         }
         if (!again) break;
         if (spin_fail(c, spins, code, 1)) break;
@@ -233,7 +265,8 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     float* red = reinterpret_cast<float*>(ring + (size_t)A.ring_slots * kPSlot);      // [kPCW][4 groups][R] float4
     float* stat = red + kPCW * 4 * kRMaxRows * 4;    // [2][kPCW][16]
     float* resid = stat + 2 * kPCW * 16;             // [R] float4: the residual of this workgroup's four output columns
-    float* gbs = resid + kRMaxRows * 4;              // [kPCW][32 gain quads | 32 bias quads] of the LayerNorm a phase applies
+    float* resid2 = resid + kRMaxRows * 4;           // [2][R] float4: x' of the eight columns this workgroup finishes in phase E
+    float* gbs = resid2 + 2 * kRMaxRows * 4;              // [kPCW][32 gain quads | 32 bias quads] of the LayerNorm a phase applies
     float* ascr = gbs + kPCW * 64 * 4;               // attention: q[256] | m_s[8] | l_s[8] | o_s[8][256]
     unsigned* ctl = reinterpret_cast<unsigned*>(ascr + 256 + 16 + kPCW * 256);
     if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0u;
@@ -294,16 +327,31 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) =
                 *reinterpret_cast<const float4*>((lane < 32 ? Lp->ln1_w : Lp->ln1_b) + (s0 * KK + (lane & 31)) * 4);
             if (l == 0) {
+                if (A.tok_in) {          // a decode step: the row is built from the embedding tables here (one launch less per step)
+                    const int bs = n < A.rows ? n / A.T : 0;
+                    const int tok = min(max(A.tok_in[n < A.rows ? n : 0], 0), A.vocab - 1), mp = A.mel_pos_idx[A.slots[bs]];
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i) {
+                        const int q = (s0 + i) * KK + kk;
+                        const float4 e = *reinterpret_cast<const float4*>(A.mel_emb + (size_t)tok * D + q * 4);
+                        const float4 p = *reinterpret_cast<const float4*>(A.mel_pos + (size_t)mp * D + q * 4);
+                        xv[i] = n < A.rows ? make_float4(e.x + p.x, e.y + p.y, e.z + p.z, e.w + p.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i) {
+                        const int q = (s0 + i) * KK + kk;
+                        xv[i] = n < A.rows ? *reinterpret_cast<const float4*>(A.x + (size_t)n * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            } else {                     // x = the two K-half planes of the previous layer's mlp c_proj (plane 0 carries residual + bias)
+                pu32x4 raw[NSX], raw1[NSX];
+                rgather2<NSX>(c, brs, po + kRoffX1 * 4 + s0 * 1024 + lane * 16, 1024, R * D * 4, raw, raw1, 100 + l);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
-                    const int q = (s0 + i) * KK + kk;
-                    xv[i] = n < A.rows ? *reinterpret_cast<const float4*>(A.x + (size_t)n * D + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 a = as_f4(raw[i]), b2 = as_f4(raw1[i]);
+                    xv[i] = make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w);
                 }
-            } else {
-                pu32x4 raw[NSX];
-                rgather<NSX>(c, brs, po + kRoffX1 * 4 + s0 * 1024 + lane * 16, 1024, raw, 100 + l, NSX <= A.poll_all);
-#pragma unroll
-                for (int i = 0; i < NSX; ++i) xv[i] = as_f4(raw[i]);
             }
             stamp_at(l, 0, 0);
             // residual of this workgroup's output columns [4 wg, 4 wg + 4) of phase C: k-quad wg of x
@@ -695,6 +743,16 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 for (int i = 0; i < NSX; ++i) xv[i] = as_f4(raw[i]);
             }
             stamp_at(l, 3, 0);
+            // residual of phase E: this workgroup finishes columns [8 (wg / 2), +8) there = k-quads 2 (wg / 2) + {0, 1} of x'
+#pragma unroll
+            for (int ge = 0; ge < 2; ++ge) {
+                const int qe = (wg >> 1) * 2 + ge, sq = qe / KK;
+                if (sq >= s0 && sq < s0 + NSX && kk == qe % KK) {
+#pragma unroll
+                    for (int i = 0; i < NSX; ++i)
+                        if (i == sq - s0) *reinterpret_cast<float4*>(resid2 + (ge * kRMaxRows + n) * 4) = xv[i];
+                }
+            }
             float mean_, rstd_;
             {
                 float s = 0.f;
@@ -789,93 +847,88 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             }
             stamp_at(l, 3, 1);
         }
-        // =================== E: mlp c_proj -> x = x' + ... ===================
+        // =================== E: mlp c_proj, columns [8 cb, +8) over K-half kh -> plane kh of x = x' + ... ===================
+        // (workgroup (cb, kh) = (wg / 2, wg % 2): half of h to gather -- 128 KB instead of 256 KB at 16 rows, the largest hand-off of the
+        //  layer -- for one more plane in the next phase-A gather; two independent accumulator groups)
         {
             GVC_PHASE_BEGIN();
             const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
-            const int s0 = wave * NSH;
-            const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + wg * 4);
-            pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            // the wave's K-slice of h: NSH 16-byte pieces per lane.  One sentinel piece is polled, then EVERYTHING else is requested at
-            // once (16 rows: 32 pieces = 128 registers) and each 16-step chunk is completed (dirty pieces re-requested) right before
-            // its MFMAs: one memory round trip for the whole slice once the data is there
-            constexpr int NCK = NSH / 16;
-            static_assert(NSH % 16 == 0, "the mlp c_proj slice of a wave is cut in 16-step chunks");
-            pu32x4 raw[NCK][16];
-            const int goff = pc + kRoffHH * 4 + s0 * 1024 + lane * 16;
+            constexpr int NSE = NSH / 2;                             // MFMA steps per wave over 2048 inputs (16 rows: 16, 8 rows: 8)
+            const int cb = wg >> 1, kh = wg & 1;
+            const int sl = wave * NSE;                               // first step inside the K-half
+            const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + cb * 8 + (wave & 1) * 4);
+            pf32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            pu32x4 raw[NSE];
+            rgather<NSE>(c, brs, pc + kRoffHH * 4 + (kh * kPCW * NSE + sl) * 1024 + lane * 16, 1024, raw, 500 + l, NSE <= A.poll_all);
+            stamp_at(l, 4, 0);
             {
-                unsigned spins = 0;
-                while (true) {
-                    raw[0][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, 0, 16);
-                    if (__all(rclean(raw[0][0]))) break;
-                    if (spin_fail(c, spins, 500 + l, 1)) break;
+                // group ge lies in fills fs + 2 ge, fs + 2 ge + 1 (32 KiB of fp32); the wave's NSE steps sit inside one fill
+                const unsigned boff = (unsigned)sl * STEPB;
+                wait_fill(c, fs + 2 + (boff >> 14));
+                const char* wb0 = ring + (((boff & 16383u) + (lane & LMASK) * 16) >> WB);
+                const char* w0 = wb0 + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot;
+                const char* w1 = wb0 + (size_t)((fs + 2 + (boff >> 14)) & rmask) * kPSlot;
+                float4 wc0 = ldw4<WB>(w0), wc1 = ldw4<WB>(w1), wn0, wn1;
+#pragma unroll
+                for (int i = 0; i < NSE; ++i) {
+                    if (i + 1 < NSE) { wn0 = ldw4<WB>(w0 + (((i + 1) * STEPB) >> WB)); wn1 = ldw4<WB>(w1 + (((i + 1) * STEPB) >> WB)); }
+                    const float4 hv = as_f4(raw[i]);
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc0.x, hv.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc1.x, hv.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc0.y, hv.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc1.y, hv.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc0.z, hv.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc1.z, hv.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc0.w, hv.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc1.w, hv.w, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wc0 = wn0; wc1 = wn1;
                 }
             }
 #pragma unroll
-            for (int ck = 0; ck < NCK; ++ck) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (ck + i > 0) raw[ck][i] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, (ck * 16 + i) * 1024, 16);
-            }
-#pragma unroll
-            for (int ck = 0; ck < NCK; ++ck) {
-                {
-                    unsigned spins = 0;
-                    while (true) {
-                        bool again = false;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i)
-                            if (__any(!rclean(raw[ck][i]))) { raw[ck][i] = __builtin_amdgcn_raw_buffer_load_b128(brs, goff, (ck * 16 + i) * 1024, 16); again = true; }
-                        if (!again) break;
-                        if (spin_fail(c, spins, 510 + l, 1)) break;
-                    }
-                }
-                if (ck == 0) stamp_at(l, 4, 0);
-                const unsigned boff = (unsigned)(s0 + ck * 16) * STEPB;      // byte offset inside the 64 KiB group
-                wait_fill(c, fs + ((boff + 16 * STEPB - 1) >> 14));
-                {
-                    // (a chunk of 16 steps lies inside one 16 KiB ring slot: 16 steps x 256 / 512 bytes <= 8 KiB)
-                    const char* wbase = ring + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot + (((boff & 16383u) + (lane & LMASK) * 16) >> WB);
-                    float4 wc = ldw4<WB>(wbase), wn;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        if (i + 1 < 16) wn = ldw4<WB>(wbase + (((i + 1) * STEPB) >> WB));
-                        const float4 hv = as_f4(raw[ck][i]);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.x, hv.x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.y, hv.y, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.z, hv.z, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wc.w, hv.w, acc1, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        wc = wn;
-                    }
-                }
-            }
-            {
-                const float4 r = make_float4(kk_sum<R>(acc0[0] + acc1[0]), kk_sum<R>(acc0[1] + acc1[1]), kk_sum<R>(acc0[2] + acc1[2]),
-                                             kk_sum<R>(acc0[3] + acc1[3]));
-                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + 0) * kRMaxRows + n) * 4) = r;
+            for (int ge = 0; ge < 2; ++ge) {
+                const float4 r = make_float4(kk_sum<R>(acc[ge][0]), kk_sum<R>(acc[ge][1]), kk_sum<R>(acc[ge][2]), kk_sum<R>(acc[ge][3]));
+                if (kk == 0) *reinterpret_cast<float4*>(red + ((wave * 4 + ge) * kRMaxRows + n) * 4) = r;
             }
             fs += 4;
             phase_done();
             cbar(c);
-            if (wave == 0 && lane < R) {
-                const int rn = lane;
-                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + 0) * kRMaxRows + rn) * 4);
+            if (wave < 2 && lane < R) {
+                const int ge = wave, rn = lane;
+                float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + ge) * kRMaxRows + rn) * 4);
 #pragma unroll
                 for (int w = 1; w < kPCW; ++w) {
-                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + 0) * kRMaxRows + rn) * 4);
+                    const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + ge) * kRMaxRows + rn) * 4);
                     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
                 }
-                const float4 bi = bpre;
-                const float4 xr = *reinterpret_cast<const float4*>(resid + rn * 4);
-                s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
+                if (kh == 0) {                               // plane 0 carries the residual x' and the bias
+                    const float4 bi = bpre;
+                    const float4 xr = *reinterpret_cast<const float4*>(resid2 + (ge * kRMaxRows + rn) * 4);
+                    s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int fl = (wg / KK) * 64 + (((rn >> 2) * KK + (wg % KK)) * 4 + (rn & 3));
-                const int eo = kRoffX1 * 4 + fl * 16;
+                const int q = cb * 2 + ge;
+                const int fl = (q / KK) * 64 + (((rn >> 2) * KK + (q % KK)) * 4 + (rn & 3));
+                const int eo = (kRoffX1 + kh * R * D) * 4 + fl * 16;
                 rpublish(brs, pc + eo, po + eo, s);
-                if (l == A.n_layer - 1 && rn < A.rows) *reinterpret_cast<float4*>(A.x + (size_t)rn * D + wg * 4) = s;
             }
             stamp_at(l, 4, 1);
+        }
+    }
+    // =================== output rows: x of the last layer = its two planes, written row-major by workgroup 0 ===================
+    if (wg == 0) {
+        asm volatile("" : "+v"(c.lane));
+        const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
+        const int s0 = wave * NSX;
+        const int pl = ((A.n_layer - 1) & 1) * kRParFloats * 4;
+        pu32x4 raw[NSX], raw1[NSX];
+        rgather2<NSX>(c, brs, pl + kRoffX1 * 4 + s0 * 1024 + lane * 16, 1024, R * D * 4, raw, raw1, 600);
+        if (n < A.rows) {
+#pragma unroll
+            for (int i = 0; i < NSX; ++i) {
+                const float4 a = as_f4(raw[i]), b2 = as_f4(raw1[i]);
+                *reinterpret_cast<float4*>(A.x + (size_t)n * D + ((s0 + i) * KK + kk) * 4) = make_float4(a.x + b2.x, a.y + b2.y, a.z + b2.z, a.w + b2.w);
+            }
         }
     }
 #undef GVC_PHASE_BEGIN

@@ -392,10 +392,12 @@ def test_generate_groups_equals_separate_generate_calls():
     sep = [m.gpt.generate(c, t, **kw) for c, t in groups]
     for a, b in zip(joint, sep):
         assert torch.equal(a, b), (a, b)
-    # sampling: the groups run one after another (the per-row random streams keep their numbering)
+    # sampling: the groups run one after another, each class with its own random stream (seed + 7919 * class index: with one shared
+    # seed every class would draw the same per-row sequences), the rows of a class keeping the counter RNG's per-row numbering
     kw_s = dict(kw, top_k=15, seed=7)
-    for a, b in zip(m.gpt.generate_groups(groups, **kw_s), [m.gpt.generate(c, t, **kw_s) for c, t in groups]):
-        assert torch.equal(a, b)
+    sampled = m.gpt.generate_groups(groups, **kw_s)
+    for gi, ((c, t), a) in enumerate(zip(groups, sampled)):
+        assert torch.equal(a, m.gpt.generate(c, t, **dict(kw_s, seed=7 + 7919 * gi)))
     # through the offline driver: six utterances of 2.5 s at seg_len 2 s -> a class of full segments and a class of 0.5 s tails
     sr = m.content_sample_rate
     wavs = [synth.synth_audio(300 + i, "src", int(2.5 * sr)) for i in range(6)]
