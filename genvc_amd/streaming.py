@@ -13,7 +13,14 @@ per open stream and, at every `step()`, batches whatever the open streams need n
     `handle_chunks` does inside `synthesize_utt_streaming`.
 
 Each stream produces the tokens and the waveform of `synthesize_utt_streaming(model, its_source, its_reference,
-seg_len)` at top_k = 1.  With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in
+seg_len)` at top_k = 1.
+
+`left_context_s` (extension beyond the reference, SURVEY.md 8f row f4: "chunked ContentVec with left context"): the reference feeds
+ContentVec one segment at a time, so the first frames of every segment see no past (its positional conv spans +-64 frames =
+1.3 s, its attention the whole input, its layer-0 GroupNorm statistics the whole input).  With `left_context_s > 0` a stream keeps
+that many seconds of its already fed source audio (a multiple of 320 samples, ContentVec's hop) and extracts the features of
+[kept past | new segment], passing only the segment's frames on to the content tokeniser; frame i of the window starts at sample
+320 i, so the segment's frames are exactly the last ones.  The default (0) is the reference's behaviour.  With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in
 the call, not in the utterance.
 """
 import torch
@@ -31,11 +38,13 @@ class _Session:
         self.done = 0              # tokens generated for the current segment
         self.prev = self.overlap = None
         self.tokens = []           # per segment: int64 [1, n]
+        self.past = None           # left context: the tail of the source audio fed so far [1, <= ctx samples]
 
 
 class StreamSessions:
-    def __init__(self, model, max_sessions=8, group=8):
+    def __init__(self, model, max_sessions=8, group=8, left_context_s=0.0):
         m = self.m = model
+        self.ctx = int(round(left_context_s * model.content_sample_rate / 320.0)) * 320       # whole ContentVec hops
         g = m.gpt
         g._need_engine()
         self.eng = g.engine
@@ -80,6 +89,24 @@ class StreamSessions:
     def idle(self):
         return all(not s.decoding and not s.queue for s in self.sessions.values())
 
+    @torch.inference_mode()
+    def segment_features(self, ss, wav):
+        """ContentVec features of the new segments `wav` [B, n] (one per session of `ss`).  With left context each stream's kept past is
+        put in front of its segment and only the segment's frames are returned (streams go one by one: their pasts differ)."""
+        m = self.m
+        if self.ctx == 0:
+            return m.content_extractor.extract_content_features(wav)
+        n_frames = (wav.shape[1] - 400) // 320 + 1              # frames of the segment alone (HuBERT conv stack: receptive field 400, hop 320)
+        outs = []
+        for i, x in enumerate(ss):
+            seg = wav[i:i + 1]
+            win = seg if x.past is None else torch.cat([x.past, seg], 1)
+            f = m.content_extractor.extract_content_features(win)
+            outs.append(f[:, f.shape[1] - n_frames:])
+            keep = win[:, max(0, win.shape[1] - self.ctx):]
+            x.past = keep[:, keep.shape[1] % 320:].contiguous()  # a whole number of hops: the next segment's frames stay aligned
+        return torch.cat(outs, 0)
+
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def step(self):
@@ -94,7 +121,7 @@ class StreamSessions:
         for (n, cached), sids in starts.items():
             ss = [self.sessions[i] for i in sids]
             wav = torch.cat([s.queue.pop(0) for s in ss], 0)
-            feat = m.content_extractor.extract_content_features(wav)
+            feat = self.segment_features(ss, wav)
             codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
             cond = torch.cat([s.cond for s in ss], 0)
             prefix = eng.prefix_embeddings(cond.to(torch.float32).contiguous(), codes.to(torch.int32).contiguous())

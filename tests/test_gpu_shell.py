@@ -409,3 +409,46 @@ def test_generate_groups_equals_separate_generate_calls():
     finally:
         m.gpt.generate_groups = joint_fn
     assert both.shape == ref.shape and both.shape[:2] == (6, 2) and torch.equal(both, ref)
+
+
+def test_stream_sessions_left_context_contentvec():
+    """row f4 remainder: chunked ContentVec with left context behind StreamSessions.  (i) With the whole past kept, the features
+    of a segment are exactly the last frames of ContentVec run on the utterance up to the end of that segment (frame i starts at
+    sample 320 i: the kept past is a whole number of hops); (ii) against the features of the WHOLE utterance -- which the
+    reference's segment-wise extraction (no context) only approximates -- the error shrinks when context is added; (iii) the
+    default (no context) is the reference's behaviour bit for bit."""
+    from genvc_amd.streaming import StreamSessions
+    m = tiny_model(3)
+    sr = m.content_sample_rate
+    src = synth.synth_audio(91, "src", 4 * sr).to(m.device)
+    segs = [src[:, i * sr:(i + 1) * sr] for i in range(4)]
+    whole = m.content_extractor.extract_content_features(src)
+
+    class _S:
+        past = None
+
+    def run(ctx_s):
+        ss = StreamSessions(m, max_sessions=2, group=8, left_context_s=ctx_s)
+        x = _S()
+        return ss, [ss.segment_features([x], sg) for sg in segs]
+
+    ss0, f0 = run(0.0)
+    for sg, f in zip(segs, f0):
+        assert torch.equal(f, m.content_extractor.extract_content_features(sg))
+    ss_all, fa = run(10.0)
+    n_seg = f0[0].shape[1]
+    for i in range(1, 4):
+        pre = m.content_extractor.extract_content_features(src[:, :(i + 1) * sr])
+        np.testing.assert_allclose(fa[i].cpu().numpy(), pre[:, pre.shape[1] - n_seg:].cpu().numpy(), atol=1e-5)
+    # frames of segment i in the whole-utterance features: frame j of the utterance starts at sample 320 j
+    def err(fs):
+        e = []
+        for i in range(1, 4):
+            j0 = i * sr // 320
+            n = min(n_seg, whole.shape[1] - j0)
+            e.append(float((fs[i][:, :n] - whole[:, j0:j0 + n]).abs().mean()))
+        return sum(e) / len(e)
+    _, f2 = run(2.0)
+    assert err(f2) < err(f0), (err(f2), err(f0))
+    assert err(fa) <= err(f2) * 1.05, (err(fa), err(f2))
+    _m.clear()
