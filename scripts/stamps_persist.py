@@ -9,7 +9,7 @@ from genvc_amd.engine import GptEngine
 Tc = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 dims = gcfg.gpt_dims(gcfg.DEFAULT_MODEL_ARGS)
 w = synth.make_weights(1, synth.gpt_weight_spec(dims), device="cuda")
-eng = GptEngine(dims, max_slots=8, max_rows=4096); eng.bind(w)
+eng = GptEngine(dims, max_slots=8, max_rows=4096, weight_dtype=os.environ.get("GVC_WD", "fp32")); eng.bind(w)
 dev = "cuda"
 cond = synth.uniform(1, "c", (1, 32, 1024), 1.0).to(dev)
 codes = synth.integers(1, "k", (1, Tc), 256).to(dev).int()

@@ -347,3 +347,66 @@ def test_one_stream_step_bf16_storage_vs_oracle_on_rounded_weights(d, H, Tc, n, 
     assert first >= n // 2
     np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
     eng.close()
+
+
+def test_rows_step_ragged_eos_follows_the_reference_loop():
+    """stream_generator.py:861-874 over several streams on the one-launch rows step: a stream that has emitted the stop token keeps
+    emitting it (pad = stop), the others go on, the loop ends when every stream has stopped; the EOS step's latent is produced.
+    The stop bias is raised until greedy decoding ends within a few steps at different steps per stream; against the oracle's loop."""
+    from test_gpu_gpt import run_generate
+    from oracle import genvc_oracle as O
+    dims = gcfg.gpt_dims(WIDE2)
+    w = synth.make_weights(11, synth.gpt_weight_spec(dims), device="cuda")
+    B = 5
+    cond = synth.uniform(11, "cond_latents", (B, 32, 1024), 1.0)
+    codes = synth.integers(11, "content_codes", (B, 9), 256)
+    w["mel_head.bias"][1025] = 4.0           # (found by a sweep: the five streams stop at steps 1, 1, 3, 37, 28)
+    wc = {k: v.cpu() for k, v in w.items()}
+    ref_t, ref_l, _ = O.generate(wc, dims, cond, codes, GREEDY, max_new=40, stop_on_eos=True)
+    ends = [int((ref_t[b] == 1025).nonzero()[0]) if (ref_t[b] == 1025).any() else -1 for b in range(B)]
+    assert ref_t.shape[1] < 40 and min(ends) >= 1 and len(set(ends)) >= 3, (ref_t.shape, ends)
+    found = (4.0, ref_t, ref_l)
+    from genvc_amd.engine import GptEngine
+    eng = GptEngine(dims, max_slots=8, max_rows=4096)
+    eng.bind(w)
+    _, toks, lats = run_generate(eng, dims, cond, codes, 40, group=1)
+    assert eng.decode_variant() == 5
+    ref_t, ref_l = found[1], found[2]
+    assert toks.shape[1] == ref_t.shape[1], (toks.shape, ref_t.shape)       # the loop ends at the step where the last stream stops
+    assert torch.equal(toks.long(), ref_t)
+    # latents: every step of a stream up to and including its EOS step
+    for b in range(B):
+        e = int((ref_t[b] == 1025).nonzero()[0])
+        np.testing.assert_allclose(lats[b, :e + 1].numpy(), ref_l[b, :e + 1].numpy(), atol=1e-4)
+    eng.close()
+
+
+def test_rows_step_kv_cache_overflow_is_reported():
+    """eager decode steps of several streams that fill the KV cache: the position is not advanced past the cache and the next
+    call reports it (GVC_ERR_STATE, 'full'), exactly as on the other decode paths; after a reset the slots are usable again"""
+    from genvc_amd._lib import GenvcHipError
+    from genvc_amd.engine import GptEngine
+    dims = dict(gcfg.gpt_dims(WIDE2), max_seq=64)
+    w = synth.make_weights(3, synth.gpt_weight_spec(dims), device="cuda")
+    eng = GptEngine(dims, max_slots=4, max_rows=512)
+    eng.bind(w)
+    dev = "cuda"
+    B = 3
+    cond = synth.uniform(1, "c", (B, 32, 1024), 1.0).to(dev)
+    codes = synth.integers(1, "k", (B, 9), 256).to(dev).int()
+    prefix = eng.prefix_embeddings(cond, codes)                       # 44 cached positions after the prefill
+    slots = torch.arange(B, device=dev, dtype=torch.int32)
+    eng.prefill(slots, prefix, want_outputs=False)
+    tok = torch.zeros(B, device=dev, dtype=torch.int32)
+    before = eng.rows_step_launches()
+    with pytest.raises(GenvcHipError, match="full"):
+        for _ in range(30):
+            eng.decode_step(slots, tok)
+            torch.cuda.synchronize()
+    assert eng.rows_step_launches() > before
+    eng.reset(slots)
+    eng.prefill(slots, prefix, want_outputs=False)
+    eng.decode_step(slots, tok)
+    torch.cuda.synchronize()
+    eng.health()
+    eng.close()
