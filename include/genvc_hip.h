@@ -156,8 +156,12 @@ int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride,
  * max_keys = cached positions of the longest of these streams once the call has run (prefix + 1 + steps so far + n_steps);
  * the library picks the kernel variant for that context length and returns GVC_ERR_STATE when it would overflow the KV
  * cache (max_seq).  0 = unknown: ids_stride (which must then cover the whole run of the stream) is taken as the bound.
- * With one fp32 stream on a full MI355X the whole decode step is ONE launch (csrc/persist_kernel.h): a hand-off of that
- * launch that times out (not all of its 256 workgroups resident) makes the NEXT call return GVC_ERR_STATE.
+ * On a full MI355X (256 CUs) the decode step of ONE stream is ONE launch (csrc/persist_kernel.h; fp32, bf16 weights, bf16 weights
+ * + bf16 KV cache; d_model 1024 or 512 for the bf16 modes) and the step of 2..16 streams runs its whole block stack in ONE launch
+ * (csrc/persist_rows.h; d_model 1024, 4 heads of 256, an even layer count); other shapes and batch sizes take the
+ * launch-per-phase paths.  A hand-off of a one-launch step that times out (not all of its 256 workgroups resident: another
+ * process or stream holds CUs) is reported ONCE -- by gvc_gpt_health, else by the next call -- as GVC_ERR_STATE, and the context
+ * continues on the launch-per-phase paths (see gvc_gpt_health).  Eight consecutive steps are captured per graph.
  * ------------------------------------------------------------------------------------------ */
 int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                      int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
@@ -165,8 +169,9 @@ int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids
                      int32_t lat_stride, gvc_stream s);
 
 /* Which decode step the last gvc_gpt_generate call replayed (diagnostic): 0 none yet, 1 launch-per-phase with split-key attention,
- * 2 launch-per-phase with the fused short-context attention launch, 3 the one-launch step (one fp32 stream), 4 the MFMA rows path
- * (>= 5 streams, launch per phase), 5 the one-launch rows step (2..16 fp32 streams, csrc/persist_rows.h). */
+ * 2 launch-per-phase with the fused short-context attention launch, 3 the one-launch step (one stream), 4 the MFMA rows path
+ * (launch per phase: 17+ streams, or shapes the one-launch rows step does not serve), 5 the one-launch rows step (2..16 streams,
+ * csrc/persist_rows.h). */
 int gvc_gpt_decode_variant(gvc_gpt* ctx);
 /* Diagnostic: how many one-launch rows steps (csrc/persist_rows.h: 2..16 rows that continue cached sequences -- batched decode
  * steps, the uncached rows of a streaming chunk's prefill) this context has issued; a step captured into the generation loop's
