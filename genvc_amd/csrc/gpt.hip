@@ -257,7 +257,7 @@ struct gvc_gpt {
     unsigned long long* r_dbg = nullptr;   // GVC_PERSIST_STAMPS
     size_t r_lds = 0;
     int rows_keys_hint = 0;           // cached positions the longest stream of the running call reaches (set by the entry points)
-    int r_split1 = 128, r_split2 = 288;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
+    int r_split1 = 0, r_split2 = 0;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
 };
 
 static int gemv_init();
@@ -817,7 +817,10 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     A.tok_in = tok_in; A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.mel_pos_idx = c->st.mel_pos; A.vocab = c->dm.vocab;
     static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
     A.poll_all = poll_all;
-    A.split1 = c->r_split1; A.split2 = c->r_split2;
+    // keys of a (row, head) over 2 / 4 workgroups: 8 rows from 80 / 160 cached positions (one 80-key pass per workgroup; 744 vs 766 us
+    // per step at 48-112 keys, 815 vs 827 at 110-250), 16 rows from 128 / 288 (their chunk merge gathers 64 KB per chunk: 1068 vs 1104 us)
+    A.split1 = c->r_split1 > 0 ? c->r_split1 : (rows <= 8 ? 80 : 128);
+    A.split2 = c->r_split2 > 0 ? c->r_split2 : (rows <= 8 ? 160 : 288);
     const dim3 grid(persist_test_grid()), block(kPThreads);
 #define GVC_ROWS_LAUNCH(WBv, KVBv)                                                                        \
     do {                                                                                                  \

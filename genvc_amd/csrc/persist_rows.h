@@ -193,6 +193,38 @@ __device__ __forceinline__ void rgather2(PCtx& c, __amdgpu_buffer_rsrc_t rs, int
     }
 }
 
+// NC key chunks of NL pieces each plus their {m, l} pieces in ONE round trip: a sentinel piece is polled, then everything is requested
+// together (what is still poison is re-requested)
+template <int NC, int NL>
+__device__ __forceinline__ void rgather_chunks(PCtx& c, __amdgpu_buffer_rsrc_t rs, int off, int stride, int coff, int mloff, int mlcoff,
+                                               pu32x4 (&v)[NC][NL], pu32x4 (&ml)[NC], int code) {
+    unsigned spins = 0;
+    while (true) {
+        v[0][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+        if (__all(rclean(v[0][0]))) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (cc + i > 0) v[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + cc * coff, i * stride, 16);
+        ml[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff + cc * mlcoff, 0, 16);
+    }
+    while (true) {
+        bool again = false;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                if (cc + i > 0 && __any(!rclean(v[cc][i]))) { v[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + cc * coff, i * stride, 16); again = true; }
+            if (__any(!rclean(ml[cc]))) { ml[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff + cc * mlcoff, 0, 16); again = true; }
+        }
+        if (!again) break;
+        if (spin_fail(c, spins, code, 1)) break;
+    }
+}
+
 // sum over the lanes that share (row group, row-in-group) and differ in the k position: lane = (g KK + kk) 4 + t
 template <int R>
 __device__ __forceinline__ float kk_sum(float v) {
@@ -490,7 +522,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const size_t head_off = ((size_t)slot * H + h) * A.max_seq * HD * ESZ;
             const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Lp->kcache) + head_off, head_bytes);
             const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Lp->vcache) + head_off, head_bytes);
-            constexpr int U = 8;                                 // keys per wave and pass: 64 keys of the chunk per pass
+            constexpr int U = 10;                                // keys per wave and pass: 80 keys of the chunk per pass
             float4 kr[U], vr[U];
             auto load_pass = [&](int kb) {                       // keys kb + wave + 8 u of the cache (written by earlier launches)
                 const int voff = ((kb + wave) * HD + lane * 4) * ESZ;
@@ -619,18 +651,26 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int s0 = wave * NSX;
             float4 ov[NSX];
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->proj_b + wg * 4);
-            {
+            if (nch == 1) {                                  // one chunk: its partial IS the head output (already normalised)
                 pu32x4 raw[NSX];
                 rgather<NSX>(c, brs, pc + kRoffOP * 4 + s0 * 1024 + lane * 16, 1024, raw, 300 + l, NSX <= A.poll_all);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
-            }
-            if (nch > 1) {                                   // the wave's 32 k-quads lie in head wave / 2
+            } else {
+                // several chunks: merge their (o, m, l) in chunk order; the wave's 32 k-quads lie in head wave / 2.  All chunks are
+                // requested in one round trip (16 rows x 4 chunks: two trips of two chunks, 64 registers each)
                 const int hh = wave >> 1;
-                pu32x4 ml[1];
-                rgather<1>(c, brs, pc + (kRoffML + ((0 * kRMaxRows + n) * 4 + hh) * 4) * 4, 0, ml, 310 + l);
-                float M = __uint_as_float(ml[0].x), Wt = __uint_as_float(ml[0].y);       // running max, sum of weights (at max M)
-                auto merge = [&](const pu32x4 (&raw)[NSX], float mc, float lc) {
+                const int ooff = pc + kRoffOP * 4 + s0 * 1024 + lane * 16, ocoff = R * D * 4;
+                const int moff = pc + (kRoffML + (n * 4 + hh) * 4) * 4, mcoff = kRMaxRows * 4 * 4 * 4;
+                float M = 0.f, Wt = 0.f;                     // running max, sum of weights (at max M)
+                auto merge = [&](const pu32x4 (&raw)[NSX], pu32x4 mlv, bool first) {
+                    const float mc = __uint_as_float(mlv.x), lc = __uint_as_float(mlv.y);
+                    if (first) {
+#pragma unroll
+                        for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
+                        M = mc; Wt = lc;
+                        return;
+                    }
                     const float Mn = fmaxf(M, mc);
                     const float wa = Wt * __expf(M - Mn), wb = lc * __expf(mc - Mn);
                     const float tot = wa + wb;
@@ -643,43 +683,20 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     }
                     M = Mn; Wt = tot;
                 };
-                auto chunk_off = [&](int cc) { return pc + (kRoffOP + cc * R * D) * 4 + s0 * 1024 + lane * 16; };
-                auto ml_off = [&](int cc) { return pc + (kRoffML + ((cc * kRMaxRows + n) * 4 + hh) * 4) * 4; };
                 if (nch == 2) {
-                    pu32x4 raw[NSX];
-                    rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
-                    rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
-                    merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
-                } else if constexpr (NSX <= 4) {             // four chunks, 8 rows: chunk 2 requested while chunk 1 is merged
-                    pu32x4 raw[NSX], rawb[NSX], mlb[1];
-                    rgather<NSX>(c, brs, chunk_off(1), 1024, raw, 320 + l);
-                    rgather<1>(c, brs, ml_off(1), 0, ml, 330 + l);
-#pragma unroll
-                    for (int i = 0; i < NSX; ++i) rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, chunk_off(2), i * 1024, 16);
-                    merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
-                    rgather<NSX>(c, brs, chunk_off(3), 1024, raw, 321 + l);
-                    rgather<1>(c, brs, ml_off(3), 0, mlb, 331 + l);
-                    {   // chunk 2 was requested before chunk 1 was merged: re-request what was still poison then
-                        unsigned spins = 0;
-                        while (true) {
-                            bool again = false;
-#pragma unroll
-                            for (int i = 0; i < NSX; ++i)
-                                if (__any(!rclean(rawb[i]))) { rawb[i] = __builtin_amdgcn_raw_buffer_load_b128(brs, chunk_off(2), i * 1024, 16); again = true; }
-                            if (!again) break;
-                            if (spin_fail(c, spins, 322 + l, 1)) break;
-                        }
-                    }
-                    rgather<1>(c, brs, ml_off(2), 0, ml, 332 + l);
-                    merge(rawb, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
-                    merge(raw, __uint_as_float(mlb[0].x), __uint_as_float(mlb[0].y));
-                } else {                                     // four chunks, 16 rows (registers): one after the other
+                    pu32x4 raw[2][NSX], ml[2];
+                    rgather_chunks<2, NSX>(c, brs, ooff, 1024, ocoff, moff, mcoff, raw, ml, 320 + l);
+                    merge(raw[0], ml[0], true); merge(raw[1], ml[1], false);
+                } else if constexpr (NSX <= 4) {
+                    pu32x4 raw[4][NSX], ml[4];
+                    rgather_chunks<4, NSX>(c, brs, ooff, 1024, ocoff, moff, mcoff, raw, ml, 320 + l);
+                    merge(raw[0], ml[0], true); merge(raw[1], ml[1], false); merge(raw[2], ml[2], false); merge(raw[3], ml[3], false);
+                } else {
 #pragma unroll 1
-                    for (int cc = 1; cc < 4; ++cc) {
-                        pu32x4 raw[NSX];
-                        rgather<NSX>(c, brs, chunk_off(cc), 1024, raw, 320 + l);
-                        rgather<1>(c, brs, ml_off(cc), 0, ml, 330 + l);
-                        merge(raw, __uint_as_float(ml[0].x), __uint_as_float(ml[0].y));
+                    for (int c2 = 0; c2 < 4; c2 += 2) {
+                        pu32x4 raw[2][NSX], ml[2];
+                        rgather_chunks<2, NSX>(c, brs, ooff + c2 * ocoff, 1024, ocoff, moff + c2 * mcoff, mcoff, raw, ml, 320 + l);
+                        merge(raw[0], ml[0], c2 == 0); merge(raw[1], ml[1], false);
                     }
                 }
             }
