@@ -11,6 +11,7 @@
 // conv_post (Cout = 1) + tanh is a small dedicated kernel.  Weight-norm (weight_g, weight_v) is folded by the loader.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -87,150 +88,265 @@ __global__ void k_hf_tile_bias(const float* b, float* out, int Co, int s) {
     if (i < Co * s) out[i] = b[i % Co];
 }
 
-// wav[b][t] = tanh(bias + sum_{j<k, ci} lrelu(x[t - pad + j][ci], slope) * w[j*C + ci])      (conv_post, Cout = 1)
-__global__ void k_conv_post_tanh(const float* x, const float* w, const float* bias, float* wav, int T, int C, int k,
-                                 float slope) {
-    extern __shared__ float ws[];
-    for (int i = threadIdx.x; i < k * C; i += blockDim.x) ws[i] = w[i];
-    __syncthreads();
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
-    const int pad = (k - 1) / 2;
-    const float* xr = x + ((size_t)b * (T + 2 * kHfPad) + kHfPad + t - pad) * C;
-    float acc = bias[0];
-    for (int i = 0; i < k * C; i += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + i);
-        acc = fmaf(v.x > 0.f ? v.x : v.x * slope, ws[i], acc);
-        acc = fmaf(v.y > 0.f ? v.y : v.y * slope, ws[i + 1], acc);
-        acc = fmaf(v.z > 0.f ? v.z : v.z * slope, ws[i + 2], acc);
-        acc = fmaf(v.w > 0.f ? v.w : v.w * slope, ws[i + 3], acc);
+// wav[b][t] = tanh(bias + sum_{j<k, ci} lrelu(xin[t - pad + j][ci], slope) * w[j*C + ci]),  xin = x_scale * ((p0 + p1) + p2)
+// (conv_post, Cout = 1, fed by the three ResBlock planes of the last stage).  A workgroup owns 64 samples: their 64 + k - 1
+// input rows go to LDS once; four lanes share a sample (a quarter of the channels each) and combine with two shuffles.
+template <int NSUM>
+__global__ __launch_bounds__(256) void k_conv_post_tanh(const float* x, long long x_ss, float x_scale, const float* w, const float* bias,
+                                                        float* wav, int T, int C, int k, float slope) {
+    extern __shared__ float ws[];                  // [k*C] weights, then [64 + k - 1][C + 1] input rows
+    float* Xs = ws + k * C;
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int pad = (k - 1) / 2, R = 64 + k - 1, C4 = C / 4, XS = C + 1;
+    const int last_row = T + 2 * kHfPad - 1;
+    const float* xb = x + (size_t)b * (T + 2 * kHfPad) * C;
+    constexpr int UL = 3;
+    for (int i0 = tid; i0 < R * C4; i0 += 256 * UL) {
+        float4 xv[UL][NSUM];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int i = min(i0 + u * 256, R * C4 - 1);
+            const float* src = xb + (size_t)min(kHfPad + t0 - pad + i / C4, last_row) * C + (i % C4) * 4;
+#pragma unroll
+            for (int p = 0; p < NSUM; ++p) xv[u][p] = *reinterpret_cast<const float4*>(src + (size_t)p * x_ss);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int i = i0 + u * 256;
+            if (i < R * C4) {
+                float4 v = xv[u][0];
+                if constexpr (NSUM > 1) {
+#pragma unroll
+                    for (int p = 1; p < NSUM; ++p) { v.x += xv[u][p].x; v.y += xv[u][p].y; v.z += xv[u][p].z; v.w += xv[u][p].w; }
+                    v.x *= x_scale; v.y *= x_scale; v.z *= x_scale; v.w *= x_scale;
+                }
+                float* d = &Xs[(i / C4) * XS + (i % C4) * 4];
+                d[0] = v.x > 0.f ? v.x : v.x * slope; d[1] = v.y > 0.f ? v.y : v.y * slope;
+                d[2] = v.z > 0.f ? v.z : v.z * slope; d[3] = v.w > 0.f ? v.w : v.w * slope;
+            }
+        }
     }
-    wav[(size_t)b * T + t] = tanhf(acc);
+    for (int i = tid; i < k * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int t = tid >> 2, q = tid & 3, cq = C / 4;
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float* xr = &Xs[(t + j) * XS + q * cq];
+        const float* wr = &ws[j * C + q * cq];
+        for (int c = 0; c < cq; ++c) acc = fmaf(xr[c], wr[c], acc);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (q == 0 && t0 + t < T) wav[(size_t)b * T + t0 + t] = tanhf(acc + bias[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// ResBlock convs (C = 32, 64 or 128 channels in and out, k <= 7 taps, dilation <= 12): the whole
-// K = k*C extent is small, so instead of the tiled GEMM's k-loop (one global->LDS->sync round trip per 32 columns:
-// 11-22 us for 0.1 GFLOP) a workgroup stages EVERYTHING it needs in one round trip -- the 32 + (k-1)*dil input rows of
-// its 32 output frames (leaky-ReLU applied while staging) and the full [C][k*C] weight matrix -- and then runs the
-// implicit im2col straight out of LDS.  A workgroup owns 32 frames x 32 output channels; its 4 (C = 32) or 8 (C = 64)
-// waves split the (tap, 8-channel group) steps of the reduction and combine through LDS; bias / residual(s) / scale in
-// the epilogue.  grid (T/32, C/32, B).
+// Convolutions whose whole K = taps * CI extent is small (ResBlock convs: CI = 32 / 64 / 128 channels in and out, <= 7 taps,
+// dilation <= 12; the polyphase ConvTranspose1d layers: 3 taps of CI = 256 / 128 / 64): instead of the tiled GEMM's k-loop
+// (one global->LDS->sync round trip per 32 columns: 11 us for 0.05 GFLOP) a workgroup pays ONE memory round trip:
+//   * it owns 32 (64 when CI <= 64) frames x 16 output columns; their 32 + (k-1)*dil input rows go to LDS once (leaky-ReLU -- and, for the input
+//     of a stage, the sum of the three ResBlock outputs and the 1/3 -- applied on the way in);
+//   * weights are stored in MFMA fragment order (FM16, gemm.h) and go straight from global memory into registers, 1 KiB per
+//     wave-wide load, all of a wave's loads in flight before the input rows are staged;
+//   * the NW waves split the (tap, 16-channel block) steps of the reduction (v_mfma_f32_16x16x4_f32, two M tiles share the B
+//     operand) and combine through LDS; bias and residual in the epilogue.
+// The three ResBlocks of a stage are independent given the stage input (hifigan.py:224-229: xs += resblocks[i*nk + j](x)), so
+// ONE launch runs the first conv of all three (grid.y = job x column tile) and a second launch the second convs; each ResBlock
+// writes its own output plane and the consumer of the stage adds the planes while staging, in the reference's order.
 // ---------------------------------------------------------------------------------------------
-struct ConvSmallArgs {
-    const float* x; float* y;            // padded time-major [B][T + 2*kHfPad][C]
-    const float* w; const float* b;      // [C][k*C] (column tap*C + ci), [C]
-    const float* resid; const float* resid2;
-    int T, k, dil;
-    int tap_chunk;                       // taps of the weight tile staged in LDS at a time
-    float slope, out_scale;
+// 16-frame M tiles per workgroup of k_conv_lds: 64 frames for the narrow late stages (thousands of frames: half the workgroups, every
+// one resident at once), 32 otherwise
+__host__ __device__ constexpr int conv_lds_mt(int ci, bool split) { return (ci <= 64 && !split) ? 4 : 2; }
+
+struct ConvLdsJob {
+    const float4* wp;                    // FM16 copy of [N][k*CI]
+    const float* b;                      // [N]
+    int k, dil, row_off;                 // output frame t reads input rows t + row_off + j*dil, j < k
 };
 
-typedef float hf_f32x16 __attribute__((ext_vector_type(16)));
+struct ConvLdsArgs {
+    // input: padded time-major [B][T + 2*kHfPad][CI]; job j reads plane(s) at x + j*x_ps (x_ps = 0: every job reads the same input)
+    const float* x; long long x_bs, x_ps, x_ss;      // x_ss: distance between the NSUM planes that are added while staging
+    float x_scale, slope;                            // staged value = lrelu(x_scale * (p0 + p1 + p2)); x_scale only with NSUM > 1
+    // output element (t, n) of job j, batch b: y[b*y_bs + j*y_ps + y_off + t*ldy + n]; resid (nullable) is indexed the same way
+    float* y; long long y_bs, y_ps, y_off; int ldy;
+    const float* resid; long long r_ps;
+    int T, ntiles;                                   // input frames (= output rows), N / 16
+    int ldx;                                         // floats between input rows (CI, or more when the jobs are channel slices)
+    // SPLIT (conv_pre: few outputs, K = 7 * 1024): job j < split is the channel slice [j*CI, (j+1)*CI) of every tap -- x_ps = CI, weights
+    // job[0].wp + j*wp_js -- and writes RAW partial sums to plane j of y; the last workgroup to finish a tile (cnt) adds the
+    // planes in order, adds the bias and writes yf[b*yf_bs + yf_off + t*ldy + n]
+    int split; long long wp_js; int* cnt;
+    float* yf; long long yf_bs, yf_off;
+    ConvLdsJob job[3];
+};
+
 typedef float hf_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int C, int NW>
-__global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
-    // grid (T/32, C/32, B): a workgroup owns 32 frames x one 32-channel tile of the outputs; NW waves split the reduction
+template <int CI, int NW, int NSUM, bool SPLIT = false>
+__global__ __launch_bounds__(NW * 64) void k_conv_lds(const ConvLdsArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int XS = C + 4, NTH = NW * 64;
-    const int K = A.k * C;
-    const int tc = A.tap_chunk;                 // taps of W staged at a time (all of them when the tile fits in LDS)
-    const int WS = tc * C + 4;
-    const int R = 32 + (A.k - 1) * A.dil;
+    constexpr int XS = CI + 4, NTH = NW * 64, C4 = CI / 4, CB = CI / 16;
+    constexpr int MT = conv_lds_mt(CI, SPLIT), TF = 16 * MT;       // 16-frame M tiles, frames per workgroup
+    constexpr int MAXS = CI <= 64 ? 4 : 8;                          // steps per wave held in registers (7 taps: 3.5 / 3.5 / 7; ups: 6)
     float* Xs = lds;                       // [R][XS]
-    float* Ws = lds + (size_t)R * XS;      // [32][WS]: taps [tap0, tap0 + tc) of the 32-channel weight tile
-    float* red = lds;                      // [NW][16][64] after the MFMA loop (aliases Xs/Ws)
+    float* red = lds;                      // [NW][4 * MT][64] after the MFMA loop (aliases Xs)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 32, b = blockIdx.z;
-    const int pad = A.dil * (A.k - 1) / 2;
-    const size_t bs = (size_t)(A.T + 2 * kHfPad) * C;
-    const float* xb = A.x + b * bs + (size_t)(kHfPad + t0 - pad) * C;
-    // staging loops: UL requests per thread go out before the first LDS store (with a run-time trip count and one float4 per
-    // iteration the compiler emitted load / s_waitcnt vmcnt(0) / ds_write, a memory round trip per float4)
-    constexpr int UL = 8;
-    for (int i0 = tid; i0 < R * (C / 4); i0 += NTH * UL) {
-        float4 xv[UL];
+    const int jb = blockIdx.y / A.ntiles, tile = blockIdx.y - jb * A.ntiles;
+    const ConvLdsJob J = A.job[SPLIT ? 0 : jb];
+    const int t0 = blockIdx.x * TF, b = blockIdx.z;
+    const int nsteps = J.k * CB, R = TF + (J.k - 1) * J.dil;
+    // this wave's B operands: steps wave, wave + NW, ...; requested before anything else
+    const float4* wp = J.wp + (SPLIT ? (size_t)jb * A.wp_js : 0) + (size_t)tile * nsteps * 64 + lane;
+    float4 wv[MAXS];
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) wv[u] = wp[(size_t)min(wave + NW * u, nsteps - 1) * 64];
+    const float bn = J.b[tile * 16 + (lane & 15)];
+    __builtin_amdgcn_sched_barrier(0);
+    // input rows -> LDS: UL requests per thread go out before the first LDS store (rows past the buffer only feed frames >= T)
+    const int last_row = A.T + 2 * kHfPad - 1, row0 = kHfPad + t0 + J.row_off;
+    const float* xb = A.x + (size_t)b * A.x_bs + (size_t)jb * A.x_ps;
+    constexpr int UL = NSUM == 1 ? 8 : 4;
+    for (int i0 = tid; i0 < R * C4; i0 += NTH * UL) {
+        float4 xv[UL][NSUM];
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
-            const int i = min(i0 + u * NTH, R * (C / 4) - 1);
-            xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)(i / (C / 4)) * C + (i % (C / 4)) * 4);
+            const int i = min(i0 + u * NTH, R * C4 - 1);
+            const float* src = xb + (size_t)min(row0 + i / C4, last_row) * A.ldx + (i % C4) * 4;
+#pragma unroll
+            for (int p = 0; p < NSUM; ++p) xv[u][p] = *reinterpret_cast<const float4*>(src + (size_t)p * A.x_ss);
         }
         __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink every request to just above its store)
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
             const int i = i0 + u * NTH;
-            if (i < R * (C / 4)) {
-                float4 v = xv[u];
+            if (i < R * C4) {
+                float4 v = xv[u][0];
+                if constexpr (NSUM > 1) {
+#pragma unroll
+                    for (int p = 1; p < NSUM; ++p) { v.x += xv[u][p].x; v.y += xv[u][p].y; v.z += xv[u][p].z; v.w += xv[u][p].w; }
+                    v.x *= A.x_scale; v.y *= A.x_scale; v.z *= A.x_scale; v.w *= A.x_scale;
+                }
                 v.x = v.x > 0.f ? v.x : v.x * A.slope; v.y = v.y > 0.f ? v.y : v.y * A.slope;
                 v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
-                *reinterpret_cast<float4*>(&Xs[(i / (C / 4)) * XS + (i % (C / 4)) * 4]) = v;
+                *reinterpret_cast<float4*>(&Xs[(i / C4) * XS + (i % C4) * 4]) = v;
             }
         }
     }
-    hf_f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int m = lane & 31, half = lane >> 5;
-    for (int tap0 = 0; tap0 < A.k; tap0 += tc) {
-        const int nt = min(tc, A.k - tap0), kc4 = nt * C / 4;
-        if (tap0 > 0) __syncthreads();             // the previous chunk of W has been consumed
-        // wave w stages rows w, w + NW, ... of the weight tile; the 32 / NW row requests of a column step go out together
-        constexpr int WR = 32 / NW;
-        for (int kk = lane; kk < kc4; kk += 64) {
-            hf_f32x4 wv[WR];
-#pragma unroll
-            for (int j = 0; j < WR; ++j)
-                wv[j] = *reinterpret_cast<const hf_f32x4*>(A.w + (size_t)(n0 + wave + NW * j) * K + tap0 * C + kk * 4);
-            __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink every request to just above its store)
-#pragma unroll
-            for (int j = 0; j < WR; ++j) *reinterpret_cast<hf_f32x4*>(&Ws[(wave + NW * j) * WS + kk * 4]) = wv[j];
-        }
-        __syncthreads();
-        const int steps = nt * (C / 8);
-        for (int it = wave; it < steps; it += NW) {
-            const int tl = it / (C / 8), q = it - tl * (C / 8);
-            const float4 a4 = *reinterpret_cast<const float4*>(&Xs[(m + (tap0 + tl) * A.dil) * XS + 8 * q + 4 * half]);
-            const float4 b4 = *reinterpret_cast<const float4*>(&Ws[m * WS + tl * C + 8 * q + 4 * half]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-        }
-    }
-    __syncthreads();                      // everyone is done reading Xs / Ws: the region becomes the reduction buffer
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-    __syncthreads();
-    // thread (wave, lane) finishes accumulator registers wave*16/NW .. of the tile
-    constexpr int RPW = 16 / NW;
-    const size_t ob = b * bs + (size_t)(kHfPad + t0) * C;
-    // bias and residuals of this thread's outputs are requested together, ahead of the LDS sums
-    const int n = n0 + (lane & 31);
-    const float bn = A.b[n];
-    float r1[RPW], r2[RPW];
+    // thread (wave, lane) will finish accumulator registers r = wave, wave + NW, ... of the tile -- frame 16*(r/4) + 4*(lane/16) + r%4 --
+    // and asks for its residuals now, so that the round trip hides under the matrix work
+    constexpr int RPW = 4 * MT / NW;
+    const int n = tile * 16 + (lane & 15);
+    const size_t ob = (size_t)b * A.y_bs + A.y_off + n;
+    float r1[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
-        const size_t o = ob + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * C + n;
-        r1[rr] = A.resid ? A.resid[o] : 0.f;
-        r2[rr] = A.resid2 ? A.resid2[o] : 0.f;
+        const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
+        r1[rr] = (A.resid && t0 + m < A.T) ? A.resid[ob + (size_t)jb * A.r_ps + (size_t)(t0 + m) * A.ldy] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    hf_f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+    const int fi = lane & 15, fg = lane >> 4;
+    auto step = [&](int it, const float4& w4) {
+        const int tap = it / CB, cb = it - tap * CB;
+        const float* xp = &Xs[(fi + tap * J.dil) * XS + 16 * cb + 4 * fg];
+        float4 a[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(xp + 16 * t * XS);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, w4.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, w4.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, w4.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, w4.w, acc[t], 0, 0, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u)
+        if (wave + NW * u < nsteps) step(wave + NW * u, wv[u]);
+    for (int it = wave + NW * MAXS; it < nsteps; it += NW) step(it, wp[(size_t)it * 64]);      // (more taps than any GenVC config has)
+    __syncthreads();                      // everyone is done reading Xs: the region becomes the reduction buffer
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[(wave * 4 * MT + 4 * t + v) * 64 + lane] = acc[t][v];
+    __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave * RPW + rr;
+        const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[(w * 16 + r) * 64 + lane];
-        const int mo = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const size_t o = ob + (size_t)mo * C + n;
-        v += bn;
-        if (A.resid) v += r1[rr];
-        if (A.resid2) v += r2[rr];
-        if (A.out_scale != 0.f) v *= A.out_scale;
-        A.y[o] = v;
+        for (int w = 0; w < NW; ++w) v += red[(w * 4 * MT + r) * 64 + lane];
+        if constexpr (!SPLIT) {
+            v += bn;
+            if (A.resid) v += r1[rr];
+        }
+        if (t0 + m < A.T) {
+            float* dst = A.y + ob + (size_t)jb * A.y_ps + (size_t)(t0 + m) * A.ldy;
+            // (partial sums are handed to another workgroup: write-through stores and, below, cache-bypassing loads -- a
+            // __threadfence() here writes back the whole L2 of the XCD, 50 us for this kernel)
+            if constexpr (SPLIT) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = v;
+        }
+    }
+    if constexpr (SPLIT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's partial sums have landed before its arrival is counted
+        __syncthreads();
+        if (tid == 0) {
+            int* cn = A.cnt + ((size_t)b * gridDim.x + blockIdx.x) * A.ntiles + tile;
+            const int last = __hip_atomic_fetch_add(cn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.split - 1;
+            if (last) __hip_atomic_store(cn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every slice has arrived: ready for the next call
+            reinterpret_cast<int*>(lds)[0] = last;          // (the reduction buffer was consumed before the barrier above)
+        }
+        __syncthreads();
+        if (!reinterpret_cast<const int*>(lds)[0]) return;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
+            if (t0 + m >= A.T) continue;
+            const float* pp = A.y + ob + (size_t)(t0 + m) * A.ldy;
+            float v = 0.f;
+            for (int p = 0; p < A.split; ++p) v += __hip_atomic_load(pp + (size_t)p * A.y_ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.yf[(size_t)b * A.yf_bs + A.yf_off + (size_t)(t0 + m) * A.ldy + n] = v + bn;
+        }
+    }
+}
+
+// conv_pre weights [Co][Ci][k] -> per channel slice s (CS channels) the FM16 copy of [Co][k*CS] (column tap*CS + c): [Ci/CS][FM16]
+__global__ void k_hf_pack_slices(const float* w, float* out, int Co, int Ci, int k, int CS) {
+    const int K = k * CS;
+    const size_t per = (size_t)Co * K, n4 = per * (Ci / CS) / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i * 4 / per);
+        const size_t r = i * 4 - (size_t)sl * per;
+        const int n = (int)(r / K), kc = (int)(r % K), tap = kc / CS, cl = kc % CS;
+        const float* src = w + ((size_t)n * Ci + sl * CS + cl) * k + tap;
+        *reinterpret_cast<float4*>(out + (size_t)sl * per + fm16_index(n, kc, K)) = make_float4(src[0], src[k], src[2 * k], src[3 * k]);
+    }
+}
+
+// p0 = scale * ((p0 + p1) + p2): the stage output for a consumer that cannot add the ResBlock planes itself (tiled GEMM)
+__global__ void k_sum_planes(float* p, long long ps, float scale, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<float4*>(p)[i];
+        const float4 b = reinterpret_cast<const float4*>(p + ps)[i], c = reinterpret_cast<const float4*>(p + 2 * ps)[i];
+        a.x = ((a.x + b.x) + c.x) * scale; a.y = ((a.y + b.y) + c.y) * scale;
+        a.z = ((a.z + b.z) + c.z) * scale; a.w = ((a.w + b.w) + c.w) * scale;
+        reinterpret_cast<float4*>(p)[i] = a;
+    }
+}
+
+// [N][K] row-major -> FM16 (gemm.h)
+__global__ void k_hf_to_fm16(const float* src, float* dst, int N, int K) {
+    const size_t n4 = (size_t)N * K / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / (K / 4)), k = (int)(i % (K / 4)) * 4;
+        *reinterpret_cast<float4*>(dst + fm16_index(n, k, K)) = *reinterpret_cast<const float4*>(src + (size_t)n * K + k);
     }
 }
 
@@ -238,8 +354,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_small(const ConvSmallArgs A) {
 
 using namespace gvc;
 
-struct HfConv { float *w = nullptr, *b = nullptr; int Co = 0, Ci = 0, k = 0, dil = 1; };
-struct HfUp { float *w = nullptr, *b = nullptr, *braw = nullptr; int Ci = 0, Co = 0, k = 0, s = 0, pad = 0, dmin = 0, ntap = 0; };
+struct HfConv { float *w = nullptr, *b = nullptr, *wp = nullptr; int Co = 0, Ci = 0, k = 0, dil = 1; };     // wp: FM16 copy for k_conv_lds, null: shape not eligible
+struct HfUp { float *w = nullptr, *b = nullptr, *braw = nullptr, *wp = nullptr; int Ci = 0, Co = 0, k = 0, s = 0, pad = 0, dmin = 0, ntap = 0; };
+// a stage input: one buffer, or the nsum ResBlock planes (ss floats apart) whose scaled sum it is
+struct HfIn { const float* x = nullptr; int nsum = 1; long long ss = 0; float scale = 1.f; };
+struct HfPlan { hipGraphExec_t ge = nullptr; HfIn out; int T = 0; };
 
 struct gvc_hifigan {
     gvc_hifigan_dims dm;
@@ -250,17 +369,22 @@ struct gvc_hifigan {
     int n_expected = 0;
     float* x0 = nullptr;                     // interpolated input
     float* x1 = nullptr;                     // conv_pre output
-    std::vector<float*> U, R, S0, S1;        // per stage
+    // per stage: U = upsampled signal; R, S = n_kernels planes each (outputs of the first ResBlock convs / of the ResBlocks; the
+    // launch-per-conv path keeps its running sum in planes 0 and 1 of S)
+    std::vector<float*> U, R, S;
+    std::vector<long long> plane;            // floats per plane
     float* work = nullptr;
     long long work_cap = 0;
+    float* pre_wp = nullptr;                 // conv_pre weights as 64-channel slices in FM16 (k_conv_lds<.., SPLIT>), null: shape not eligible
+    int* cnt = nullptr;                      // arrival counters of the split conv_pre, zero between calls
     std::vector<void*> allocs;
     int cur_T0 = -1, cur_B = -1;
-    // the GEMM chain between the input staging and conv_post only touches context buffers: it is captured once per
-    // (B, frames) and replayed (about 30 launches of a few microseconds each are host-bound when launched eagerly)
-    std::map<long long, hipGraphExec_t> graphs;
+    // the chain between the input staging and conv_post only touches context buffers: it is captured once per
+    // (B, frames) and replayed (a dozen launches of a few microseconds each are host-bound when launched eagerly)
+    std::map<long long, HfPlan> graphs;
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
-    int small_conv = 1;                      // GVC_VOCODER_SMALL_CONV=0: ResBlock convs of the last stages through the tiled GEMM
+    int small_conv = 1;                      // GVC_VOCODER_SMALL_CONV=0: every conv through the tiled GEMM, one launch per conv
 };
 
 static int halloc(gvc_hifigan* c, float** p, size_t n) {
@@ -269,6 +393,16 @@ static int halloc(gvc_hifigan* c, float** p, size_t n) {
     c->allocs.push_back(*p);
     return GVC_OK;
 }
+
+static bool lds_ci_ok(int ci) { return ci == 32 || ci == 64 || ci == 128 || ci == 256; }
+// LDS bytes of k_conv_lds: the input rows, later the reduction buffer
+static size_t conv_lds_bytes(int ci, int k, int dil, bool split = false) {
+    const int mt = conv_lds_mt(ci, split);
+    const size_t stage = (size_t)(16 * mt + (k - 1) * dil) * (ci + 4), red = (size_t)8 * 4 * mt * 64;
+    return (stage > red ? stage : red) * sizeof(float);
+}
+constexpr size_t kConvLdsMax = 150 * 1024;
+constexpr int kPreSlice = 64, kPreCounters = 4096;
 
 extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** out) {
     GVC_REQUIRE(dims && out, GVC_ERR_ARG, "gvc_hifigan_create: null argument");
@@ -281,9 +415,14 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     auto mkconv = [&](HfConv& w, int Co, int Ci, int k, int dil) {
         w.Co = Co; w.Ci = Ci; w.k = k; w.dil = dil;
         int r = halloc(c, &w.w, (size_t)Co * Ci * k);
+        if (!r && Co == Ci && lds_ci_ok(Ci) && conv_lds_bytes(Ci, k, dil) <= kConvLdsMax) r = halloc(c, &w.wp, (size_t)Co * Ci * k);
         return r ? r : halloc(c, &w.b, Co);
     };
     rc = mkconv(c->pre, D.up_init_ch, D.in_dim, 7, 1);
+    if (!rc && D.in_dim % kPreSlice == 0 && D.up_init_ch % 16 == 0) {
+        rc = halloc(c, &c->pre_wp, (size_t)D.up_init_ch * D.in_dim * 7);
+        if (!rc) rc = halloc(c, reinterpret_cast<float**>(&c->cnt), kPreCounters);
+    }
     int ch = D.up_init_ch;
     size_t T = D.max_frames;
     const size_t B = D.max_batch;
@@ -301,9 +440,9 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
                 if (kk >= 0 && kk < u.k) { if (d < dmin) dmin = d; if (d > dmax) dmax = d; }
             }
         u.dmin = dmin; u.ntap = dmax - dmin + 1;
-        if ((rc = halloc(c, &u.w, (size_t)u.s * u.Co * u.ntap * u.Ci)) || (rc = halloc(c, &u.b, (size_t)u.s * u.Co)) ||
-            (rc = halloc(c, &u.braw, u.Co)))
-            break;
+        const size_t nw = (size_t)u.s * u.Co * u.ntap * u.Ci;
+        if ((rc = halloc(c, &u.w, nw)) || (rc = halloc(c, &u.b, (size_t)u.s * u.Co)) || (rc = halloc(c, &u.braw, u.Co))) break;
+        if (lds_ci_ok(u.Ci) && (u.s * u.Co) % 16 == 0 && conv_lds_bytes(u.Ci, u.ntap, 1) <= kConvLdsMax && (rc = halloc(c, &u.wp, nw))) break;
         c->ups.push_back(u);
         ch = u.Co;
         T *= u.s;
@@ -314,10 +453,10 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
                 GVC_REQUIRE(rc || w.dil * (w.k - 1) / 2 <= kHfPad, GVC_ERR_UNSUPPORTED, "hifigan: conv padding exceeds %d", kHfPad);
                 c->res.push_back(w);
             }
-        float *u_, *r_, *s0, *s1;
-        const size_t n = B * (T + 2 * kHfPad) * ch;
-        if (!rc && !(rc = halloc(c, &u_, n)) && !(rc = halloc(c, &r_, n)) && !(rc = halloc(c, &s0, n)) && !(rc = halloc(c, &s1, n))) {
-            c->U.push_back(u_); c->R.push_back(r_); c->S0.push_back(s0); c->S1.push_back(s1);
+        float *u_, *r_, *s_;
+        const size_t n = B * (T + 2 * kHfPad) * ch, np = n * (D.n_kernels > 2 ? D.n_kernels : 2);
+        if (!rc && !(rc = halloc(c, &u_, n)) && !(rc = halloc(c, &r_, np)) && !(rc = halloc(c, &s_, np))) {
+            c->U.push_back(u_); c->R.push_back(r_); c->S.push_back(s_); c->plane.push_back((long long)n);
         }
     }
     if (!rc) rc = mkconv(c->post, 1, ch, 7, 1);
@@ -327,10 +466,13 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     if (rc) { gvc_hifigan_destroy(c); return rc; }
     if (getenv("GVC_VOCODER_GRAPH")) c->use_graph = atoi(getenv("GVC_VOCODER_GRAPH"));
     if (getenv("GVC_VOCODER_SMALL_CONV")) c->small_conv = atoi(getenv("GVC_VOCODER_SMALL_CONV"));
-    // up to ~150 KB of dynamic LDS (64 channels, 7 taps): raise the per-kernel limit once, outside any capture
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_small<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // up to ~150 KB of dynamic LDS: raise the per-kernel limits once, outside any capture
+#define GVC_HF_ATTR(CI, NW)                                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<CI, NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<CI, NW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    GVC_HF_ATTR(32, 4) GVC_HF_ATTR(64, 8) GVC_HF_ATTR(128, 8) GVC_HF_ATTR(256, 8)
+#undef GVC_HF_ATTR
+    (void)hipGetLastError();
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     *out = c;
     return GVC_OK;
@@ -338,7 +480,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
 
 extern "C" int gvc_hifigan_destroy(gvc_hifigan* c) {
     if (!c) return GVC_OK;
-    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second.ge);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -355,6 +497,10 @@ static int hf_bind_conv(HfConv& w, bool is_bias, const float* src, int64_t numel
                 (long long)w.Co * w.Ci * w.k, (long long)numel);
     hipLaunchKernelGGL(k_hf_repack_conv, dim3(512), dim3(256), 0, s, src, w.w, w.Co, w.Ci, w.k);
     GVC_LAUNCH_CHECK();
+    if (w.wp) {
+        hipLaunchKernelGGL(k_hf_to_fm16, dim3(256), dim3(256), 0, s, w.w, w.wp, w.Co, w.k * w.Ci);
+        GVC_LAUNCH_CHECK();
+    }
     return GVC_OK;
 }
 
@@ -369,7 +515,13 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
     int rc = GVC_OK;
     bool known = is_bias || is_w;
     if (!known) return GVC_OK;
-    if (n.rfind("conv_pre.", 0) == 0) rc = hf_bind_conv(c->pre, is_bias, src, numel, name, s);
+    if (n.rfind("conv_pre.", 0) == 0) {
+        rc = hf_bind_conv(c->pre, is_bias, src, numel, name, s);
+        if (!rc && is_w && c->pre_wp) {
+            hipLaunchKernelGGL(k_hf_pack_slices, dim3(512), dim3(256), 0, s, src, c->pre_wp, c->pre.Co, c->pre.Ci, c->pre.k, kPreSlice);
+            GVC_LAUNCH_CHECK();
+        }
+    }
     else if (n.rfind("conv_post.", 0) == 0) rc = hf_bind_conv(c->post, is_bias, src, numel, name, s);
     else if (n.rfind("ups.", 0) == 0) {
         const int i = atoi(n.c_str() + 4);
@@ -385,6 +537,10 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
             hipLaunchKernelGGL(k_hf_repack_convT, dim3(512), dim3(256), 0, s, src, u.w, u.Ci, u.Co, u.k, u.s, u.pad, u.dmin,
                                u.ntap);
             GVC_LAUNCH_CHECK();
+            if (u.wp) {
+                hipLaunchKernelGGL(k_hf_to_fm16, dim3(256), dim3(256), 0, s, u.w, u.wp, u.s * u.Co, u.ntap * u.Ci);
+                GVC_LAUNCH_CHECK();
+            }
         }
     } else if (n.rfind("resblocks.", 0) == 0) {
         const int bi = atoi(n.c_str() + 10);
@@ -403,31 +559,23 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
 
 extern "C" int gvc_hifigan_missing_weights(gvc_hifigan* c) { return c ? c->n_expected - (int)c->bound.size() : -1; }
 
-// out rows [PAD, PAD+T) = epilogue(conv(lrelu?(src)))
-// LDS bytes of k_conv_small with `tc` taps of the weight tile resident
-static size_t conv_small_lds(const HfConv& w, int tc) {
-    const size_t R = 32 + (size_t)(w.k - 1) * w.dil;
-    const size_t stage = R * (w.Ci + 4) + (size_t)32 * ((size_t)tc * w.Ci + 4), red = (size_t)8 * 16 * 64;
-    return (stage > red ? stage : red) * sizeof(float);
+// grid (frame tiles, jobs x column tiles, batch)
+static int launch_conv_lds(int ci, int nsum, const ConvLdsArgs& A, int njobs, int B, size_t lds, hipStream_t s) {
+    const dim3 grid(cdiv(A.T, 16 * conv_lds_mt(ci, false)), njobs * A.ntiles, B);
+#define GVC_HF_LAUNCH(CI, NW)                                                                            \
+    if (ci == CI) {                                                                                      \
+        if (nsum == 1) hipLaunchKernelGGL((k_conv_lds<CI, NW, 1>), grid, dim3(NW * 64), lds, s, A);     \
+        else hipLaunchKernelGGL((k_conv_lds<CI, NW, 3>), grid, dim3(NW * 64), lds, s, A);               \
+    }
+    GVC_HF_LAUNCH(32, 4) GVC_HF_LAUNCH(64, 8) GVC_HF_LAUNCH(128, 8) GVC_HF_LAUNCH(256, 8)
+#undef GVC_HF_LAUNCH
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
 }
 
-static int hf_conv(gvc_hifigan* c, const HfConv& w, const float* src, float* dst, int T, int B, float a_slope,
-                   const float* resid, const float* resid2, float out_scale, hipStream_t s) {
-    if (c->small_conv && w.Ci == w.Co && (w.Ci == 32 || w.Ci == 64 || w.Ci == 128) && T % 32 == 0 && a_slope != 0.f) {
-        int tc = w.k;                                    // as many taps of W at a time as fit beside the input rows
-        while (tc > 1 && conv_small_lds(w, tc) > 150 * 1024) --tc;
-        if (conv_small_lds(w, tc) <= 150 * 1024) {
-            ConvSmallArgs A;
-            A.x = src; A.y = dst; A.w = w.w; A.b = w.b; A.resid = resid; A.resid2 = resid2; A.T = T; A.k = w.k; A.dil = w.dil;
-            A.tap_chunk = tc; A.slope = a_slope; A.out_scale = out_scale;
-            const size_t lds = conv_small_lds(w, tc);
-            if (w.Ci == 32) hipLaunchKernelGGL((k_conv_small<32, 4>), dim3(T / 32, 1, B), dim3(256), lds, s, A);
-            else if (w.Ci == 64) hipLaunchKernelGGL((k_conv_small<64, 8>), dim3(T / 32, 2, B), dim3(512), lds, s, A);
-            else hipLaunchKernelGGL((k_conv_small<128, 8>), dim3(T / 32, 4, B), dim3(512), lds, s, A);
-            GVC_LAUNCH_CHECK();
-            return GVC_OK;
-        }
-    }
+// tiled-GEMM conv: out rows [PAD, PAD+T) = epilogue(conv(lrelu?(src)))
+static int hf_conv_gemm(gvc_hifigan* c, const HfConv& w, const float* src, float* dst, int T, int B, float a_slope,
+                        const float* resid, const float* resid2, float out_scale, hipStream_t s) {
     GemmArgs G;
     memset(&G, 0, sizeof(G));
     const int pad = w.dil * (w.k - 1) / 2;
@@ -445,48 +593,114 @@ static int hf_conv(gvc_hifigan* c, const HfConv& w, const float* src, float* dst
     return launch_gemm_cap(G, B, c->work_cap, s);
 }
 
-// conv_pre .. last ResBlock sum; returns the final activation buffer and its length
-static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, const float** x_out, int* T_out) {
+// conv_pre .. last ResBlock; returns what conv_post reads (a buffer, or the ResBlock planes of the last stage) and its length
+static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int* T_out) {
     int rc;
     const gvc_hifigan_dims& D = c->dm;
-    if ((rc = hf_conv(c, c->pre, c->x0, c->x1, T0, B, 0.f, nullptr, nullptr, 0.f, s))) return rc;
-    const float* x = c->x1;
+    const int nk = D.n_kernels;
+    const HfConv& pc = c->pre;
+    const int nsplit = pc.Ci / kPreSlice, pre_tiles = pc.Co / 16;
+    if (c->small_conv && c->pre_wp && (long long)nsplit * B * T0 * pc.Co <= c->work_cap && B * cdiv(T0, 32) * pre_tiles <= kPreCounters) {
+        // conv_pre: 16 output columns x a 64-channel slice of the 7 taps per workgroup, slices combined by the last one to finish
+        ConvLdsArgs A;
+        memset(&A, 0, sizeof(A));
+        A.x = c->x0; A.x_bs = (long long)(T0 + 2 * kHfPad) * pc.Ci; A.x_ps = kPreSlice; A.ldx = pc.Ci; A.x_scale = 1.f; A.slope = 1.f;
+        A.y = c->work; A.y_bs = (long long)T0 * pc.Co; A.y_ps = (long long)B * T0 * pc.Co; A.ldy = pc.Co;
+        A.yf = c->x1; A.yf_bs = (long long)(T0 + 2 * kHfPad) * pc.Co; A.yf_off = (long long)kHfPad * pc.Co;
+        A.T = T0; A.ntiles = pre_tiles; A.split = nsplit; A.wp_js = (long long)pre_tiles * pc.k * (kPreSlice / 16) * 64; A.cnt = c->cnt;
+        A.job[0].wp = reinterpret_cast<const float4*>(c->pre_wp); A.job[0].b = pc.b; A.job[0].k = pc.k; A.job[0].dil = 1;
+        A.job[0].row_off = -(pc.k - 1) / 2;
+        hipLaunchKernelGGL((k_conv_lds<kPreSlice, 8, 1, true>), dim3(cdiv(T0, 32), nsplit * pre_tiles, B), dim3(512),
+                           conv_lds_bytes(kPreSlice, pc.k, 1, true), s, A);
+        GVC_LAUNCH_CHECK();
+    } else if ((rc = hf_conv_gemm(c, pc, c->x0, c->x1, T0, B, 0.f, nullptr, nullptr, 0.f, s))) return rc;
+    HfIn in;
+    in.x = c->x1;
     int T = T0;
     for (int i = 0; i < D.n_ups; ++i) {
         const HfUp& u = c->ups[i];
-        // upsample: M = T input frames, N = s*Co, window of ntap input rows starting at q + dmin
-        GemmArgs G;
-        memset(&G, 0, sizeof(G));
-        G.A = x + (size_t)(kHfPad + u.dmin) * u.Ci; G.lda = u.Ci; G.a_batch_stride = (long long)(T + 2 * kHfPad) * u.Ci;
-        G.a_act = AACT_LRELU; G.a_slope = 0.1f;
-        G.Wt = u.w; G.ldw = u.ntap * u.Ci;
-        const int To = T * u.s;
-        G.C = c->U[i] + (size_t)kHfPad * u.Co; G.ldc = u.s * u.Co; G.c_batch_stride = (long long)(To + 2 * kHfPad) * u.Co;
-        G.M = T; G.N = u.s * u.Co; G.K = u.ntap * u.Ci; G.work = c->work; G.e.bias = u.b;
-        if ((rc = launch_gemm_cap(G, B, c->work_cap, s))) return rc;
-        T = To;
-        float* acc[2] = {c->S0[i], c->S1[i]};
-        const float* prev = nullptr;
-        for (int j = 0; j < D.n_kernels; ++j) {
-            const HfConv& ca = c->res[(i * D.n_kernels + j) * 2], &cb = c->res[(i * D.n_kernels + j) * 2 + 1];
-            // ResBlock2: r = U + conv_a(lrelu(U)); out_j = r + conv_b(lrelu(r)); running sum over j, /n_kernels at the end
-            if ((rc = hf_conv(c, ca, c->U[i], c->R[i], T, B, 0.1f, c->U[i], nullptr, 0.f, s))) return rc;
-            float* dst = acc[j & 1];
-            const bool last = j == D.n_kernels - 1;
-            if ((rc = hf_conv(c, cb, c->R[i], dst, T, B, 0.1f, c->R[i], prev, last ? 1.0f / (float)D.n_kernels : 0.f, s)))
-                return rc;
-            prev = dst;
+        const int To = T * u.s, N = u.s * u.Co;
+        // upsample: T input frames x N = s*Co columns (row q of the output = frames s*q .. s*q + s - 1), ntap input rows from q + dmin
+        if (c->small_conv && u.wp && (in.nsum == 1 || in.nsum == 3)) {
+            ConvLdsArgs A;
+            memset(&A, 0, sizeof(A));
+            A.x = in.x; A.x_bs = (long long)(T + 2 * kHfPad) * u.Ci; A.ldx = u.Ci; A.x_ss = in.ss; A.x_scale = in.scale; A.slope = 0.1f;
+            A.y = c->U[i]; A.y_bs = (long long)(To + 2 * kHfPad) * u.Co; A.y_off = (long long)kHfPad * u.Co; A.ldy = N;
+            A.T = T; A.ntiles = N / 16;
+            A.job[0].wp = reinterpret_cast<const float4*>(u.wp); A.job[0].b = u.b; A.job[0].k = u.ntap; A.job[0].dil = 1; A.job[0].row_off = u.dmin;
+            if ((rc = launch_conv_lds(u.Ci, in.nsum, A, 1, B, conv_lds_bytes(u.Ci, u.ntap, 1), s))) return rc;
+        } else {
+            if (in.nsum > 1) {         // the tiled GEMM reads one buffer: add the planes in place first
+                GVC_REQUIRE(in.nsum == 3, GVC_ERR_STATE, "hifigan: %d ResBlock planes", in.nsum);
+                hipLaunchKernelGGL(k_sum_planes, dim3(256), dim3(256), 0, s, const_cast<float*>(in.x), in.ss, in.scale,
+                                   (size_t)B * (T + 2 * kHfPad) * u.Ci / 4);
+                GVC_LAUNCH_CHECK();
+            }
+            GemmArgs G;
+            memset(&G, 0, sizeof(G));
+            G.A = in.x + (size_t)(kHfPad + u.dmin) * u.Ci; G.lda = u.Ci; G.a_batch_stride = (long long)(T + 2 * kHfPad) * u.Ci;
+            G.a_act = AACT_LRELU; G.a_slope = 0.1f;
+            G.Wt = u.w; G.ldw = u.ntap * u.Ci;
+            G.C = c->U[i] + (size_t)kHfPad * u.Co; G.ldc = N; G.c_batch_stride = (long long)(To + 2 * kHfPad) * u.Co;
+            G.M = T; G.N = N; G.K = u.ntap * u.Ci; G.work = c->work; G.e.bias = u.b;
+            if ((rc = launch_gemm_cap(G, B, c->work_cap, s))) return rc;
         }
-        x = prev;
+        T = To;
+        const int ch = u.Co;
+        const HfConv* cv = &c->res[(size_t)i * nk * 2];
+        bool planes = c->small_conv && nk == 3;
+        size_t lds_a = 0, lds_b = 0;
+        for (int j = 0; j < nk && planes; ++j) {
+            planes = cv[2 * j].wp && cv[2 * j + 1].wp;
+            lds_a = std::max(lds_a, conv_lds_bytes(ch, cv[2 * j].k, cv[2 * j].dil));
+            lds_b = std::max(lds_b, conv_lds_bytes(ch, cv[2 * j + 1].k, cv[2 * j + 1].dil));
+        }
+        if (planes) {
+            // ResBlock2 j: r_j = U + conv_a(lrelu(U)); out_j = r_j + conv_b(lrelu(r_j)); the consumer adds out_0..2 and divides
+            ConvLdsArgs A;
+            memset(&A, 0, sizeof(A));
+            A.x = c->U[i]; A.x_bs = (long long)(T + 2 * kHfPad) * ch; A.ldx = ch; A.slope = 0.1f; A.x_scale = 1.f;
+            A.y = c->R[i]; A.y_bs = A.x_bs; A.y_ps = c->plane[i]; A.y_off = (long long)kHfPad * ch; A.ldy = ch;
+            A.resid = c->U[i]; A.T = T; A.ntiles = ch / 16;
+            for (int j = 0; j < nk; ++j) {
+                const HfConv& w = cv[2 * j];
+                A.job[j].wp = reinterpret_cast<const float4*>(w.wp); A.job[j].b = w.b; A.job[j].k = w.k; A.job[j].dil = w.dil;
+                A.job[j].row_off = -(w.dil * (w.k - 1) / 2);
+            }
+            if ((rc = launch_conv_lds(ch, 1, A, nk, B, lds_a, s))) return rc;
+            A.x = c->R[i]; A.x_ps = c->plane[i];
+            A.y = c->S[i];
+            A.resid = c->R[i]; A.r_ps = c->plane[i];
+            for (int j = 0; j < nk; ++j) {
+                const HfConv& w = cv[2 * j + 1];
+                A.job[j].wp = reinterpret_cast<const float4*>(w.wp); A.job[j].b = w.b; A.job[j].k = w.k; A.job[j].dil = w.dil;
+                A.job[j].row_off = -(w.dil * (w.k - 1) / 2);
+            }
+            if ((rc = launch_conv_lds(ch, 1, A, nk, B, lds_b, s))) return rc;
+            in.x = c->S[i]; in.nsum = nk; in.ss = c->plane[i]; in.scale = 1.0f / (float)nk;
+        } else {
+            // one launch per conv, running sum over j in planes 0 / 1 of S, /n_kernels folded into the last epilogue
+            float* acc[2] = {c->S[i], c->S[i] + c->plane[i]};
+            const float* prev = nullptr;
+            for (int j = 0; j < nk; ++j) {
+                if ((rc = hf_conv_gemm(c, cv[2 * j], c->U[i], c->R[i], T, B, 0.1f, c->U[i], nullptr, 0.f, s))) return rc;
+                float* dst = acc[j & 1];
+                if ((rc = hf_conv_gemm(c, cv[2 * j + 1], c->R[i], dst, T, B, 0.1f, c->R[i], prev, j == nk - 1 ? 1.0f / (float)nk : 0.f, s)))
+                    return rc;
+                prev = dst;
+            }
+            in = HfIn();
+            in.x = prev;
+        }
     }
-    *x_out = x;
+    *out = in;
     *T_out = T;
     return GVC_OK;
 }
 
 static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
     int rc;
-    const float* x = nullptr;
+    HfIn x;
     int T = 0;
     if (!c->use_graph) {
         if ((rc = hf_body(c, B, T0, s, &x, &T))) return rc;
@@ -494,28 +708,30 @@ static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
         const long long key = ((long long)B << 32) | (unsigned)T0;
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
+            HfPlan pl;
             GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-            rc = hf_body(c, B, T0, c->cap_stream, &x, &T);
+            rc = hf_body(c, B, T0, c->cap_stream, &pl.out, &pl.T);
             hipGraph_t graph = nullptr;
             hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
             if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
             GVC_CHECK_HIP(e);
-            hipGraphExec_t ge;
-            e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+            e = hipGraphInstantiate(&pl.ge, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
             GVC_CHECK_HIP(e);
-            it = c->graphs.emplace(key, ge).first;
+            it = c->graphs.emplace(key, pl).first;
         }
-        GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
-        // geometry of the final activation (what hf_body would have returned)
-        T = T0;
-        for (const HfUp& u : c->ups) T *= u.s;
-        const int nk = c->dm.n_kernels, last = (int)c->ups.size() - 1;
-        x = ((nk - 1) & 1) ? c->S1[last] : c->S0[last];
+        GVC_CHECK_HIP(hipGraphLaunch(it->second.ge, s));
+        x = it->second.out;
+        T = it->second.T;
     }
     const HfConv& p = c->post;
-    hipLaunchKernelGGL(k_conv_post_tanh, dim3(cdiv(T, 256), B), dim3(256), p.k * p.Ci * sizeof(float), s, x, p.w, p.b, wav, T,
-                       p.Ci, p.k, 0.01f);     // F.leaky_relu default slope before conv_post (hifigan.py:230)
+    GVC_REQUIRE(x.nsum == 1 || x.nsum == 3, GVC_ERR_STATE, "hifigan: %d ResBlock planes", x.nsum);
+    const size_t lds = ((size_t)p.k * p.Ci + (size_t)(64 + p.k - 1) * (p.Ci + 1)) * sizeof(float);
+    // F.leaky_relu default slope before conv_post (hifigan.py:230)
+    if (x.nsum == 1)
+        hipLaunchKernelGGL((k_conv_post_tanh<1>), dim3(cdiv(T, 64), B), dim3(256), lds, s, x.x, x.ss, x.scale, p.w, p.b, wav, T, p.Ci, p.k, 0.01f);
+    else
+        hipLaunchKernelGGL((k_conv_post_tanh<3>), dim3(cdiv(T, 64), B), dim3(256), lds, s, x.x, x.ss, x.scale, p.w, p.b, wav, T, p.Ci, p.k, 0.01f);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
@@ -530,10 +746,15 @@ static int hf_prepare(gvc_hifigan* c, int B, int T0, hipStream_t s) {
         size_t T = T0, ch = c->dm.up_init_ch;
         GVC_CHECK_HIP(hipMemsetAsync(c->x0, 0, (size_t)B * (T + 2 * kHfPad) * c->dm.in_dim * sizeof(float), s));
         GVC_CHECK_HIP(hipMemsetAsync(c->x1, 0, (size_t)B * (T + 2 * kHfPad) * ch * sizeof(float), s));
+        const int np = c->dm.n_kernels > 2 ? c->dm.n_kernels : 2;
         for (size_t i = 0; i < c->ups.size(); ++i) {
             T *= c->ups[i].s; ch = c->ups[i].Co;
             const size_t bytes = (size_t)B * (T + 2 * kHfPad) * ch * sizeof(float);
-            for (float* p : {c->U[i], c->R[i], c->S0[i], c->S1[i]}) GVC_CHECK_HIP(hipMemsetAsync(p, 0, bytes, s));
+            GVC_CHECK_HIP(hipMemsetAsync(c->U[i], 0, bytes, s));
+            for (int p = 0; p < np; ++p) {
+                GVC_CHECK_HIP(hipMemsetAsync(c->R[i] + (size_t)p * c->plane[i], 0, bytes, s));
+                GVC_CHECK_HIP(hipMemsetAsync(c->S[i] + (size_t)p * c->plane[i], 0, bytes, s));
+            }
         }
         c->cur_T0 = T0; c->cur_B = B;
     }
