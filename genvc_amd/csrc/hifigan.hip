@@ -2,12 +2,17 @@
 // ResBlock2 :119-157) with the config of configs/vocoder_configs.py:7-20, fed by the x4 linear interpolation
 // of the GPT latents (inference/inference_utils.py:81-85, 196-202).
 //
-// Everything is a GEMM on the fp32 MFMA kernel (gemm.h) over time-major activations [T + 2*PAD][C]:
+// Every layer is a matrix product over time-major activations [T + 2*PAD][C] with zero rows either side:
 //   * Conv1d(k, dilation)      A row t = taps at rows t - pad + j*dil (implicit im2col, no copy), W -> [Cout][k*Cin];
-//   * ConvTranspose1d(k, s)    ONE GEMM with N = s*Cout: row q of the output holds the s frames s*q .. s*q+s-1, which
+//   * ConvTranspose1d(k, s)    ONE product with N = s*Cout: row q of the output holds the s frames s*q .. s*q+s-1, which
 //                              IS the time-major layout of the upsampled signal; W -> [s*Cout][ntap*Cin] (polyphase);
-//   * leaky_relu on the conv inputs is applied while the A tile is staged; bias, the residual add, the running sum over
-//     the three ResBlocks and the final 1/3 are fused in the epilogue.
+//   * leaky_relu on the conv inputs is applied while the input tile is staged; bias and residual in the epilogue.
+// The streaming call (8 tokens -> 32 frames -> 8192 samples: 1.6 GFLOP, 14 MB of weights) is pure latency, so the default path
+// is 12 launches of k_conv_lds (below), each ONE memory round trip deep, captured with the input staging and conv_post in one
+// graph: conv_pre (K-split over 64-channel slices, combined by the last workgroup to arrive), per stage the upsampling layer,
+// the first convs of the three ResBlocks in one launch and the second convs in another; the consumer of a stage adds the three
+// ResBlock planes and the 1/3 while it stages its input.  184 -> 85 us per call (profiles/r03_microbench_notes.md section 9).
+// Shapes k_conv_lds does not take (and GVC_VOCODER_SMALL_CONV=0) run on the tiled fp32 MFMA GEMM of gemm.h, one launch per conv.
 // conv_post (Cout = 1) + tanh is a small dedicated kernel.  Weight-norm (weight_g, weight_v) is folded by the loader.
 #include <stdlib.h>
 
@@ -358,7 +363,14 @@ struct HfConv { float *w = nullptr, *b = nullptr, *wp = nullptr; int Co = 0, Ci 
 struct HfUp { float *w = nullptr, *b = nullptr, *braw = nullptr, *wp = nullptr; int Ci = 0, Co = 0, k = 0, s = 0, pad = 0, dmin = 0, ntap = 0; };
 // a stage input: one buffer, or the nsum ResBlock planes (ss floats apart) whose scaled sum it is
 struct HfIn { const float* x = nullptr; int nsum = 1; long long ss = 0; float scale = 1.f; };
-struct HfPlan { hipGraphExec_t ge = nullptr; HfIn out; int T = 0; };
+struct HfPlan {
+    hipGraph_t graph = nullptr; hipGraphExec_t ge = nullptr;
+    HfIn out; int T = 0;                       // what conv_post reads
+    // whole-call graphs: the nodes that carry the caller's pointers, and the pointers the executable graph holds now
+    hipGraphNode_t head = nullptr, post = nullptr;
+    dim3 head_grid, head_block, post_grid, post_block; unsigned post_lds = 0;
+    const float* in = nullptr; float* wav = nullptr;
+};
 
 struct gvc_hifigan {
     gvc_hifigan_dims dm;
@@ -384,7 +396,9 @@ struct gvc_hifigan {
     std::map<long long, HfPlan> graphs;
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
-    int small_conv = 1;                      // GVC_VOCODER_SMALL_CONV=0: every conv through the tiled GEMM, one launch per conv
+    // GVC_VOCODER_SMALL_CONV=0: every conv through the tiled GEMM, one launch per conv; 2: only the ResBlocks on k_conv_lds (conv_pre and
+    // the upsampling layers through the tiled GEMM, which reads the sum of the ResBlock planes from k_sum_planes)
+    int small_conv = 1;
 };
 
 static int halloc(gvc_hifigan* c, float** p, size_t n) {
@@ -480,7 +494,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
 
 extern "C" int gvc_hifigan_destroy(gvc_hifigan* c) {
     if (!c) return GVC_OK;
-    for (auto& kv : c->graphs) hipGraphExecDestroy(kv.second.ge);
+    for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -600,7 +614,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
     const int nk = D.n_kernels;
     const HfConv& pc = c->pre;
     const int nsplit = pc.Ci / kPreSlice, pre_tiles = pc.Co / 16;
-    if (c->small_conv && c->pre_wp && (long long)nsplit * B * T0 * pc.Co <= c->work_cap && B * cdiv(T0, 32) * pre_tiles <= kPreCounters) {
+    if (c->small_conv == 1 && c->pre_wp && (long long)nsplit * B * T0 * pc.Co <= c->work_cap && B * cdiv(T0, 32) * pre_tiles <= kPreCounters) {
         // conv_pre: 16 output columns x a 64-channel slice of the 7 taps per workgroup, slices combined by the last one to finish
         ConvLdsArgs A;
         memset(&A, 0, sizeof(A));
@@ -621,7 +635,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
         const HfUp& u = c->ups[i];
         const int To = T * u.s, N = u.s * u.Co;
         // upsample: T input frames x N = s*Co columns (row q of the output = frames s*q .. s*q + s - 1), ntap input rows from q + dmin
-        if (c->small_conv && u.wp && (in.nsum == 1 || in.nsum == 3)) {
+        if (c->small_conv == 1 && u.wp && (in.nsum == 1 || in.nsum == 3)) {
             ConvLdsArgs A;
             memset(&A, 0, sizeof(A));
             A.x = in.x; A.x_bs = (long long)(T + 2 * kHfPad) * u.Ci; A.ldx = u.Ci; A.x_ss = in.ss; A.x_scale = in.scale; A.slope = 0.1f;
@@ -698,32 +712,15 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
     return GVC_OK;
 }
 
-static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
-    int rc;
-    HfIn x;
-    int T = 0;
-    if (!c->use_graph) {
-        if ((rc = hf_body(c, B, T0, s, &x, &T))) return rc;
-    } else {
-        const long long key = ((long long)B << 32) | (unsigned)T0;
-        auto it = c->graphs.find(key);
-        if (it == c->graphs.end()) {
-            HfPlan pl;
-            GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-            rc = hf_body(c, B, T0, c->cap_stream, &pl.out, &pl.T);
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
-            if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-            GVC_CHECK_HIP(e);
-            e = hipGraphInstantiate(&pl.ge, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            GVC_CHECK_HIP(e);
-            it = c->graphs.emplace(key, pl).first;
-        }
-        GVC_CHECK_HIP(hipGraphLaunch(it->second.ge, s));
-        x = it->second.out;
-        T = it->second.T;
-    }
+enum HfHead { kHeadLatents = 0, kHeadChannelsFirst = 1 };
+
+// input staging (x4 interpolation of latents [B][n][d], or a channels-first [B][d][T0] input) -> x0
+static void hf_head(gvc_hifigan* c, int head, const float* in, int B, int T0, int n, int scale, hipStream_t s) {
+    if (head == kHeadLatents) hipLaunchKernelGGL(k_interp_linear, dim3(T0, B), dim3(256), 0, s, in, c->x0, n, c->dm.in_dim, scale, T0);
+    else hipLaunchKernelGGL(k_cf_to_time_major, dim3(cdiv(T0, 32), cdiv(c->dm.in_dim, 32), B), dim3(32, 8), 0, s, in, c->x0, c->dm.in_dim, T0);
+}
+
+static int hf_post(gvc_hifigan* c, const HfIn& x, int B, int T, float* wav, hipStream_t s) {
     const HfConv& p = c->post;
     GVC_REQUIRE(x.nsum == 1 || x.nsum == 3, GVC_ERR_STATE, "hifigan: %d ResBlock planes", x.nsum);
     const size_t lds = ((size_t)p.k * p.Ci + (size_t)(64 + p.k - 1) * (p.Ci + 1)) * sizeof(float);
@@ -734,6 +731,91 @@ static int hf_run(gvc_hifigan* c, int B, int T0, float* wav, hipStream_t s) {
         hipLaunchKernelGGL((k_conv_post_tanh<3>), dim3(cdiv(T, 64), B), dim3(256), lds, s, x.x, x.ss, x.scale, p.w, p.b, wav, T, p.Ci, p.k, 0.01f);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
+}
+
+// The whole call is ONE graph per (entry point, B, frames, scale): input staging, the conv chain, conv_post.  The caller's two
+// pointers (input, waveform) are parameters of the first and the last kernel node and are patched in the executable graph when
+// they differ from the previous call's (a stream launch after a graph launch costs an 8 us bubble; a patch is host work).
+// GVC_VOCODER_GRAPH=2: only the chain between them is captured (the round-2 scheme).
+static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int n, int scale, float* wav, hipStream_t s) {
+    int rc;
+    if (!c->use_graph) {
+        HfIn x;
+        int T = 0;
+        hf_head(c, head, in, B, T0, n, scale, s);
+        GVC_LAUNCH_CHECK();
+        if ((rc = hf_body(c, B, T0, s, &x, &T))) return rc;
+        return hf_post(c, x, B, T, wav, s);
+    }
+    const bool whole = c->use_graph == 1;
+    const long long key = ((long long)(whole ? head + 1 : 0) << 60) | ((long long)B << 44) | ((long long)(whole ? scale : 0) << 32) | (unsigned)T0;
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        HfPlan pl;
+        GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        if (whole) hf_head(c, head, in, B, T0, n, scale, c->cap_stream);
+        rc = hf_body(c, B, T0, c->cap_stream, &pl.out, &pl.T);
+        if (!rc && whole) rc = hf_post(c, pl.out, B, pl.T, wav, c->cap_stream);
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &pl.graph);
+        if (rc) { if (pl.graph) hipGraphDestroy(pl.graph); return rc; }
+        GVC_CHECK_HIP(e);
+        e = hipGraphInstantiate(&pl.ge, pl.graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) hipGraphDestroy(pl.graph);
+        GVC_CHECK_HIP(e);
+        if (whole) {
+            // the two nodes that carry the caller's pointers
+            size_t nn = 0;
+            GVC_CHECK_HIP(hipGraphGetNodes(pl.graph, nullptr, &nn));
+            std::vector<hipGraphNode_t> nodes(nn);
+            GVC_CHECK_HIP(hipGraphGetNodes(pl.graph, nodes.data(), &nn));
+            const void* head_fn = head == kHeadLatents ? reinterpret_cast<const void*>(&k_interp_linear) : reinterpret_cast<const void*>(&k_cf_to_time_major);
+            const void* post_fn = pl.out.nsum == 1 ? reinterpret_cast<const void*>(&k_conv_post_tanh<1>) : reinterpret_cast<const void*>(&k_conv_post_tanh<3>);
+            for (hipGraphNode_t nd : nodes) {
+                hipGraphNodeType ty;
+                hipKernelNodeParams kp;
+                if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+                if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) continue;
+                if (kp.func == head_fn) { pl.head = nd; pl.head_grid = kp.gridDim; pl.head_block = kp.blockDim; }
+                if (kp.func == post_fn) { pl.post = nd; pl.post_grid = kp.gridDim; pl.post_block = kp.blockDim; pl.post_lds = kp.sharedMemBytes; }
+            }
+            GVC_REQUIRE(pl.head && pl.post, GVC_ERR_STATE, "hifigan: the captured graph has no input / output kernel node");
+            pl.in = in; pl.wav = wav;
+        }
+        it = c->graphs.emplace(key, pl).first;
+    }
+    HfPlan& pl = it->second;
+    if (whole && pl.in != in) {
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.gridDim = pl.head_grid; kp.blockDim = pl.head_block;
+        float* x0 = c->x0;
+        int d = c->dm.in_dim, t0 = T0, nn = n, sc = scale;
+        void* a_lat[] = {&in, &x0, &nn, &d, &sc, &t0};
+        void* a_cf[] = {&in, &x0, &d, &t0};
+        kp.func = head == kHeadLatents ? reinterpret_cast<void*>(&k_interp_linear) : reinterpret_cast<void*>(&k_cf_to_time_major);
+        kp.kernelParams = head == kHeadLatents ? a_lat : a_cf;
+        GVC_CHECK_HIP(hipGraphExecKernelNodeSetParams(pl.ge, pl.head, &kp));
+        pl.in = in;
+    }
+    if (whole && pl.wav != wav) {
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.gridDim = pl.post_grid; kp.blockDim = pl.post_block; kp.sharedMemBytes = pl.post_lds;
+        const HfConv& p = c->post;
+        HfIn x = pl.out;
+        int T = pl.T, C = p.Ci, k = p.k;
+        float slope = 0.01f;
+        const float *pw = p.w, *pb = p.b;
+        void* a[] = {&x.x, &x.ss, &x.scale, &pw, &pb, &wav, &T, &C, &k, &slope};
+        kp.func = x.nsum == 1 ? reinterpret_cast<void*>(&k_conv_post_tanh<1>) : reinterpret_cast<void*>(&k_conv_post_tanh<3>);
+        kp.kernelParams = a;
+        GVC_CHECK_HIP(hipGraphExecKernelNodeSetParams(pl.ge, pl.post, &kp));
+        pl.wav = wav;
+    }
+    GVC_CHECK_HIP(hipGraphLaunch(pl.ge, s));
+    if (whole) return GVC_OK;
+    // round-2 scheme: staging before, conv_post after the graph (the staging kernel was enqueued by the caller of this branch)
+    return hf_post(c, pl.out, B, pl.T, wav, s);
 }
 
 static int hf_prepare(gvc_hifigan* c, int B, int T0, hipStream_t s) {
@@ -768,9 +850,11 @@ extern "C" int gvc_hifigan_forward_latents(gvc_hifigan* c, const float* latents,
     const int T0 = n * scale;
     int rc = hf_prepare(c, B, T0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_interp_linear, dim3(T0, B), dim3(256), 0, s, latents, c->x0, n, c->dm.in_dim, scale, T0);
-    GVC_LAUNCH_CHECK();
-    return hf_run(c, B, T0, wav, s);
+    if (c->use_graph == 2) {
+        hf_head(c, kHeadLatents, latents, B, T0, n, scale, s);
+        GVC_LAUNCH_CHECK();
+    }
+    return hf_run(c, B, T0, kHeadLatents, latents, n, scale, wav, s);
 }
 
 extern "C" int gvc_hifigan_forward(gvc_hifigan* c, const float* x, int32_t B, int32_t T, float* wav, gvc_stream sv) {
@@ -778,8 +862,9 @@ extern "C" int gvc_hifigan_forward(gvc_hifigan* c, const float* x, int32_t B, in
     hipStream_t s = (hipStream_t)sv;
     int rc = hf_prepare(c, B, T, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cf_to_time_major, dim3(cdiv(T, 32), cdiv(c->dm.in_dim, 32), B), dim3(32, 8), 0, s, x, c->x0,
-                       c->dm.in_dim, T);
-    GVC_LAUNCH_CHECK();
-    return hf_run(c, B, T, wav, s);
+    if (c->use_graph == 2) {
+        hf_head(c, kHeadChannelsFirst, x, B, T, T, 1, s);
+        GVC_LAUNCH_CHECK();
+    }
+    return hf_run(c, B, T, kHeadChannelsFirst, x, T, 1, wav, s);
 }

@@ -17,9 +17,22 @@ for _ in range(3):
     eng.forward_latents(lat, 4)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 50
+import time
+torch.cuda.synchronize()
 e0.record()
+h0 = time.perf_counter()
 for _ in range(reps):
     eng.forward_latents(lat, 4)
+h1 = time.perf_counter()
 e1.record()
 torch.cuda.synchronize()
-print(f"hifigan B={B} n={n}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per call")
+print(f"hifigan B={B} n={n}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us per call (host enqueue {(h1 - h0) / reps * 1e6:.1f} us per call)")
+# one call at a time, as the streaming loop issues it (the host waits for the tokens before it can enqueue the vocoder)
+t = 0.0
+for _ in range(reps):
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    eng.forward_latents(lat, 4)
+    torch.cuda.synchronize()
+    t += time.perf_counter() - h0
+print(f"  isolated call, enqueue -> synchronized: {t / reps * 1e6:.1f} us")

@@ -103,6 +103,50 @@ def test_hifigan_matches_reference(gold):
         eng.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_hifigan_fallback_paths_match_reference(gold, monkeypatch, mode):
+    """row f1: the paths behind GVC_VOCODER_SMALL_CONV -- 0: every conv on the tiled GEMM, one launch per conv, running ResBlock sum;
+    2: ResBlock planes from the LDS conv kernel, added by k_sum_planes for a tiled-GEMM upsampling layer -- and the launch-per-call
+    variants of the graph (GVC_VOCODER_GRAPH=0 / 2) against the same reference vectors as the default path"""
+    from genvc_amd.engine import HifiganEngine
+    g = gold("hifigan")
+    seed = int(g["seed"])
+    c = gcfg.DEFAULT_VOCODER
+    w = synth.make_weights(seed, synth.hifigan_weight_spec(c), device=DEV)
+    for graph in ("1", "0", "2"):
+        monkeypatch.setenv("GVC_VOCODER_SMALL_CONV", mode if graph == "1" else "1")
+        monkeypatch.setenv("GVC_VOCODER_GRAPH", graph)
+        eng = HifiganEngine(c, max_batch=2, max_frames=64)
+        eng.bind(w)
+        for B, n in ((1, 8), (2, 3), (1, 8)):
+            lat = synth.uniform(seed, f"lat_{B}_{n}", (B, n, c["input_feat_dim"]), 1.0).to(DEV)
+            np.testing.assert_allclose(eng.forward_latents(lat, 4).cpu().numpy(), g[f"full_wav_{B}_{n}"], atol=1e-4)
+        eng.close()
+
+
+def test_hifigan_whole_call_graph_follows_the_callers_buffers(gold):
+    """the whole call is one graph whose first and last kernel nodes carry the caller's pointers: different input / output
+    tensors on every call (and both entry points) must be honoured"""
+    from genvc_amd.engine import HifiganEngine
+    g = gold("hifigan")
+    seed = int(g["seed"])
+    c = gcfg.DEFAULT_VOCODER
+    eng = HifiganEngine(c, max_batch=2, max_frames=64)
+    eng.bind(synth.make_weights(seed, synth.hifigan_weight_spec(c), device=DEV))
+    ref = g["full_wav_1_8"]
+    lat0 = synth.uniform(seed, "lat_1_8", (1, 8, c["input_feat_dim"]), 1.0).to(DEV)
+    keep = []
+    for i in range(4):
+        lat = lat0.clone() if i % 2 else torch.cat([torch.zeros_like(lat0), lat0], 1)[:, 8:]      # fresh storage / an offset view
+        wav = eng.forward_latents(lat.contiguous(), 4)
+        keep.append(wav)
+        other = eng.forward_latents((lat0 * 0.5).contiguous(), 4)                                # a different input in between
+        assert float((other - wav).abs().max()) > 1e-3
+    for wav in keep:
+        np.testing.assert_allclose(wav.cpu().numpy(), ref, atol=1e-4)
+    eng.close()
+
+
 def test_resampler_matches_oracle_restatement():
     """row f2: the polyphase sinc resampler kernel against the ORACLE's float64 restatement of torchaudio.functional.resample
     (oracle/genvc_oracle.py resample; torchaudio is absent from the image, so parity with torchaudio itself is unpinned)"""
