@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "gemm.h"
+#include "conv_lds.h"
 
 namespace gvc {
 
@@ -146,182 +146,6 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const float* x, long lon
     if (q == 0 && t0 + t < T) wav[(size_t)b * T + t0 + t] = tanhf(acc + bias[0]);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Convolutions whose whole K = taps * CI extent is small (ResBlock convs: CI = 32 / 64 / 128 channels in and out, <= 7 taps,
-// dilation <= 12; the polyphase ConvTranspose1d layers: 3 taps of CI = 256 / 128 / 64): instead of the tiled GEMM's k-loop
-// (one global->LDS->sync round trip per 32 columns: 11 us for 0.05 GFLOP) a workgroup pays ONE memory round trip:
-//   * it owns 32 (64 when CI <= 64) frames x 16 output columns; their 32 + (k-1)*dil input rows go to LDS once (leaky-ReLU -- and, for the input
-//     of a stage, the sum of the three ResBlock outputs and the 1/3 -- applied on the way in);
-//   * weights are stored in MFMA fragment order (FM16, gemm.h) and go straight from global memory into registers, 1 KiB per
-//     wave-wide load, all of a wave's loads in flight before the input rows are staged;
-//   * the NW waves split the (tap, 16-channel block) steps of the reduction (v_mfma_f32_16x16x4_f32, two M tiles share the B
-//     operand) and combine through LDS; bias and residual in the epilogue.
-// The three ResBlocks of a stage are independent given the stage input (hifigan.py:224-229: xs += resblocks[i*nk + j](x)), so
-// ONE launch runs the first conv of all three (grid.y = job x column tile) and a second launch the second convs; each ResBlock
-// writes its own output plane and the consumer of the stage adds the planes while staging, in the reference's order.
-// ---------------------------------------------------------------------------------------------
-// 16-frame M tiles per workgroup of k_conv_lds: 64 frames for the narrow late stages (thousands of frames: half the workgroups, every
-// one resident at once), 32 otherwise
-__host__ __device__ constexpr int conv_lds_mt(int ci, bool split) { return (ci <= 64 && !split) ? 4 : 2; }
-
-struct ConvLdsJob {
-    const float4* wp;                    // FM16 copy of [N][k*CI]
-    const float* b;                      // [N]
-    int k, dil, row_off;                 // output frame t reads input rows t + row_off + j*dil, j < k
-};
-
-struct ConvLdsArgs {
-    // input: padded time-major [B][T + 2*kHfPad][CI]; job j reads plane(s) at x + j*x_ps (x_ps = 0: every job reads the same input)
-    const float* x; long long x_bs, x_ps, x_ss;      // x_ss: distance between the NSUM planes that are added while staging
-    float x_scale, slope;                            // staged value = lrelu(x_scale * (p0 + p1 + p2)); x_scale only with NSUM > 1
-    // output element (t, n) of job j, batch b: y[b*y_bs + j*y_ps + y_off + t*ldy + n]; resid (nullable) is indexed the same way
-    float* y; long long y_bs, y_ps, y_off; int ldy;
-    const float* resid; long long r_ps;
-    int T, ntiles;                                   // input frames (= output rows), N / 16
-    int ldx;                                         // floats between input rows (CI, or more when the jobs are channel slices)
-    // SPLIT (conv_pre: few outputs, K = 7 * 1024): job j < split is the channel slice [j*CI, (j+1)*CI) of every tap -- x_ps = CI, weights
-    // job[0].wp + j*wp_js -- and writes RAW partial sums to plane j of y; the last workgroup to finish a tile (cnt) adds the
-    // planes in order, adds the bias and writes yf[b*yf_bs + yf_off + t*ldy + n]
-    int split; long long wp_js; int* cnt;
-    float* yf; long long yf_bs, yf_off;
-    ConvLdsJob job[3];
-};
-
-typedef float hf_f32x4 __attribute__((ext_vector_type(4)));
-
-template <int CI, int NW, int NSUM, bool SPLIT = false>
-__global__ __launch_bounds__(NW * 64) void k_conv_lds(const ConvLdsArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int XS = CI + 4, NTH = NW * 64, C4 = CI / 4, CB = CI / 16;
-    constexpr int MT = conv_lds_mt(CI, SPLIT), TF = 16 * MT;       // 16-frame M tiles, frames per workgroup
-    constexpr int MAXS = CI <= 64 ? 4 : 8;                          // steps per wave held in registers (7 taps: 3.5 / 3.5 / 7; ups: 6)
-    float* Xs = lds;                       // [R][XS]
-    float* red = lds;                      // [NW][4 * MT][64] after the MFMA loop (aliases Xs)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int jb = blockIdx.y / A.ntiles, tile = blockIdx.y - jb * A.ntiles;
-    const ConvLdsJob J = A.job[SPLIT ? 0 : jb];
-    const int t0 = blockIdx.x * TF, b = blockIdx.z;
-    const int nsteps = J.k * CB, R = TF + (J.k - 1) * J.dil;
-    // this wave's B operands: steps wave, wave + NW, ...; requested before anything else
-    const float4* wp = J.wp + (SPLIT ? (size_t)jb * A.wp_js : 0) + (size_t)tile * nsteps * 64 + lane;
-    float4 wv[MAXS];
-#pragma unroll
-    for (int u = 0; u < MAXS; ++u) wv[u] = wp[(size_t)min(wave + NW * u, nsteps - 1) * 64];
-    const float bn = J.b[tile * 16 + (lane & 15)];
-    __builtin_amdgcn_sched_barrier(0);
-    // input rows -> LDS: UL requests per thread go out before the first LDS store (rows past the buffer only feed frames >= T)
-    const int last_row = A.T + 2 * kHfPad - 1, row0 = kHfPad + t0 + J.row_off;
-    const float* xb = A.x + (size_t)b * A.x_bs + (size_t)jb * A.x_ps;
-    constexpr int UL = NSUM == 1 ? 8 : 4;
-    for (int i0 = tid; i0 < R * C4; i0 += NTH * UL) {
-        float4 xv[UL][NSUM];
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const int i = min(i0 + u * NTH, R * C4 - 1);
-            const float* src = xb + (size_t)min(row0 + i / C4, last_row) * A.ldx + (i % C4) * 4;
-#pragma unroll
-            for (int p = 0; p < NSUM; ++p) xv[u][p] = *reinterpret_cast<const float4*>(src + (size_t)p * A.x_ss);
-        }
-        __builtin_amdgcn_sched_barrier(0);         // (the scheduler would sink every request to just above its store)
-#pragma unroll
-        for (int u = 0; u < UL; ++u) {
-            const int i = i0 + u * NTH;
-            if (i < R * C4) {
-                float4 v = xv[u][0];
-                if constexpr (NSUM > 1) {
-#pragma unroll
-                    for (int p = 1; p < NSUM; ++p) { v.x += xv[u][p].x; v.y += xv[u][p].y; v.z += xv[u][p].z; v.w += xv[u][p].w; }
-                    v.x *= A.x_scale; v.y *= A.x_scale; v.z *= A.x_scale; v.w *= A.x_scale;
-                }
-                v.x = v.x > 0.f ? v.x : v.x * A.slope; v.y = v.y > 0.f ? v.y : v.y * A.slope;
-                v.z = v.z > 0.f ? v.z : v.z * A.slope; v.w = v.w > 0.f ? v.w : v.w * A.slope;
-                *reinterpret_cast<float4*>(&Xs[(i / C4) * XS + (i % C4) * 4]) = v;
-            }
-        }
-    }
-    // thread (wave, lane) will finish accumulator registers r = wave, wave + NW, ... of the tile -- frame 16*(r/4) + 4*(lane/16) + r%4 --
-    // and asks for its residuals now, so that the round trip hides under the matrix work
-    constexpr int RPW = 4 * MT / NW;
-    const int n = tile * 16 + (lane & 15);
-    const size_t ob = (size_t)b * A.y_bs + A.y_off + n;
-    float r1[RPW];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
-        r1[rr] = (A.resid && t0 + m < A.T) ? A.resid[ob + (size_t)jb * A.r_ps + (size_t)(t0 + m) * A.ldy] : 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    hf_f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
-    const int fi = lane & 15, fg = lane >> 4;
-    auto step = [&](int it, const float4& w4) {
-        const int tap = it / CB, cb = it - tap * CB;
-        const float* xp = &Xs[(fi + tap * J.dil) * XS + 16 * cb + 4 * fg];
-        float4 a[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(xp + 16 * t * XS);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, w4.x, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, w4.y, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, w4.z, acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, w4.w, acc[t], 0, 0, 0);
-    };
-#pragma unroll
-    for (int u = 0; u < MAXS; ++u)
-        if (wave + NW * u < nsteps) step(wave + NW * u, wv[u]);
-    for (int it = wave + NW * MAXS; it < nsteps; it += NW) step(it, wp[(size_t)it * 64]);      // (more taps than any GenVC config has)
-    __syncthreads();                      // everyone is done reading Xs: the region becomes the reduction buffer
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) red[(wave * 4 * MT + 4 * t + v) * 64 + lane] = acc[t][v];
-    __syncthreads();
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[(w * 4 * MT + r) * 64 + lane];
-        if constexpr (!SPLIT) {
-            v += bn;
-            if (A.resid) v += r1[rr];
-        }
-        if (t0 + m < A.T) {
-            float* dst = A.y + ob + (size_t)jb * A.y_ps + (size_t)(t0 + m) * A.ldy;
-            // (partial sums are handed to another workgroup: write-through stores and, below, cache-bypassing loads -- a
-            // __threadfence() here writes back the whole L2 of the XCD, 50 us for this kernel)
-            if constexpr (SPLIT) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else *dst = v;
-        }
-    }
-    if constexpr (SPLIT) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this workgroup's partial sums have landed before its arrival is counted
-        __syncthreads();
-        if (tid == 0) {
-            int* cn = A.cnt + ((size_t)b * gridDim.x + blockIdx.x) * A.ntiles + tile;
-            const int last = __hip_atomic_fetch_add(cn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.split - 1;
-            if (last) __hip_atomic_store(cn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every slice has arrived: ready for the next call
-            reinterpret_cast<int*>(lds)[0] = last;          // (the reduction buffer was consumed before the barrier above)
-        }
-        __syncthreads();
-        if (!reinterpret_cast<const int*>(lds)[0]) return;
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = wave + NW * rr, m = 16 * (r >> 2) + 4 * (lane >> 4) + (r & 3);
-            if (t0 + m >= A.T) continue;
-            const float* pp = A.y + ob + (size_t)(t0 + m) * A.ldy;
-            float v = 0.f;
-            for (int p = 0; p < A.split; ++p) v += __hip_atomic_load(pp + (size_t)p * A.y_ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.yf[(size_t)b * A.yf_bs + A.yf_off + (size_t)(t0 + m) * A.ldy + n] = v + bn;
-        }
-    }
-}
-
 // conv_pre weights [Co][Ci][k] -> per channel slice s (CS channels) the FM16 copy of [Co][k*CS] (column tap*CS + c): [Ci/CS][FM16]
 __global__ void k_hf_pack_slices(const float* w, float* out, int Co, int Ci, int k, int CS) {
     const int K = k * CS;
@@ -408,14 +232,6 @@ static int halloc(gvc_hifigan* c, float** p, size_t n) {
     return GVC_OK;
 }
 
-static bool lds_ci_ok(int ci) { return ci == 32 || ci == 64 || ci == 128 || ci == 256; }
-// LDS bytes of k_conv_lds: the input rows, later the reduction buffer
-static size_t conv_lds_bytes(int ci, int k, int dil, bool split = false) {
-    const int mt = conv_lds_mt(ci, split);
-    const size_t stage = (size_t)(16 * mt + (k - 1) * dil) * (ci + 4), red = (size_t)8 * 4 * mt * 64;
-    return (stage > red ? stage : red) * sizeof(float);
-}
-constexpr size_t kConvLdsMax = 150 * 1024;
 constexpr int kPreSlice = 64, kPreCounters = 4096;
 
 extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** out) {
@@ -429,7 +245,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     auto mkconv = [&](HfConv& w, int Co, int Ci, int k, int dil) {
         w.Co = Co; w.Ci = Ci; w.k = k; w.dil = dil;
         int r = halloc(c, &w.w, (size_t)Co * Ci * k);
-        if (!r && Co == Ci && lds_ci_ok(Ci) && conv_lds_bytes(Ci, k, dil) <= kConvLdsMax) r = halloc(c, &w.wp, (size_t)Co * Ci * k);
+        if (!r && Co == Ci && conv_lds_ci_ok(Ci) && conv_lds_bytes(Ci, k, dil) <= kConvLdsMax) r = halloc(c, &w.wp, (size_t)Co * Ci * k);
         return r ? r : halloc(c, &w.b, Co);
     };
     rc = mkconv(c->pre, D.up_init_ch, D.in_dim, 7, 1);
@@ -456,7 +272,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
         u.dmin = dmin; u.ntap = dmax - dmin + 1;
         const size_t nw = (size_t)u.s * u.Co * u.ntap * u.Ci;
         if ((rc = halloc(c, &u.w, nw)) || (rc = halloc(c, &u.b, (size_t)u.s * u.Co)) || (rc = halloc(c, &u.braw, u.Co))) break;
-        if (lds_ci_ok(u.Ci) && (u.s * u.Co) % 16 == 0 && conv_lds_bytes(u.Ci, u.ntap, 1) <= kConvLdsMax && (rc = halloc(c, &u.wp, nw))) break;
+        if (conv_lds_ci_ok(u.Ci) && (u.s * u.Co) % 16 == 0 && conv_lds_bytes(u.Ci, u.ntap, 1) <= kConvLdsMax && (rc = halloc(c, &u.wp, nw))) break;
         c->ups.push_back(u);
         ch = u.Co;
         T *= u.s;
@@ -480,13 +296,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
     if (rc) { gvc_hifigan_destroy(c); return rc; }
     if (getenv("GVC_VOCODER_GRAPH")) c->use_graph = atoi(getenv("GVC_VOCODER_GRAPH"));
     if (getenv("GVC_VOCODER_SMALL_CONV")) c->small_conv = atoi(getenv("GVC_VOCODER_SMALL_CONV"));
-    // up to ~150 KB of dynamic LDS: raise the per-kernel limits once, outside any capture
-#define GVC_HF_ATTR(CI, NW)                                                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<CI, NW, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<CI, NW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    GVC_HF_ATTR(32, 4) GVC_HF_ATTR(64, 8) GVC_HF_ATTR(128, 8) GVC_HF_ATTR(256, 8)
-#undef GVC_HF_ATTR
-    (void)hipGetLastError();
+    conv_lds_init_attributes();
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     *out = c;
     return GVC_OK;
@@ -573,20 +383,6 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
 
 extern "C" int gvc_hifigan_missing_weights(gvc_hifigan* c) { return c ? c->n_expected - (int)c->bound.size() : -1; }
 
-// grid (frame tiles, jobs x column tiles, batch)
-static int launch_conv_lds(int ci, int nsum, const ConvLdsArgs& A, int njobs, int B, size_t lds, hipStream_t s) {
-    const dim3 grid(cdiv(A.T, 16 * conv_lds_mt(ci, false)), njobs * A.ntiles, B);
-#define GVC_HF_LAUNCH(CI, NW)                                                                            \
-    if (ci == CI) {                                                                                      \
-        if (nsum == 1) hipLaunchKernelGGL((k_conv_lds<CI, NW, 1>), grid, dim3(NW * 64), lds, s, A);     \
-        else hipLaunchKernelGGL((k_conv_lds<CI, NW, 3>), grid, dim3(NW * 64), lds, s, A);               \
-    }
-    GVC_HF_LAUNCH(32, 4) GVC_HF_LAUNCH(64, 8) GVC_HF_LAUNCH(128, 8) GVC_HF_LAUNCH(256, 8)
-#undef GVC_HF_LAUNCH
-    GVC_LAUNCH_CHECK();
-    return GVC_OK;
-}
-
 // tiled-GEMM conv: out rows [PAD, PAD+T) = epilogue(conv(lrelu?(src)))
 static int hf_conv_gemm(gvc_hifigan* c, const HfConv& w, const float* src, float* dst, int T, int B, float a_slope,
                         const float* resid, const float* resid2, float out_scale, hipStream_t s) {
@@ -619,6 +415,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
         ConvLdsArgs A;
         memset(&A, 0, sizeof(A));
         A.x = c->x0; A.x_bs = (long long)(T0 + 2 * kHfPad) * pc.Ci; A.x_ps = kPreSlice; A.ldx = pc.Ci; A.x_scale = 1.f; A.slope = 1.f;
+        A.x_row0 = kHfPad; A.x_rows = T0 + 2 * kHfPad; A.stride = 1;
         A.y = c->work; A.y_bs = (long long)T0 * pc.Co; A.y_ps = (long long)B * T0 * pc.Co; A.ldy = pc.Co;
         A.yf = c->x1; A.yf_bs = (long long)(T0 + 2 * kHfPad) * pc.Co; A.yf_off = (long long)kHfPad * pc.Co;
         A.T = T0; A.ntiles = pre_tiles; A.split = nsplit; A.wp_js = (long long)pre_tiles * pc.k * (kPreSlice / 16) * 64; A.cnt = c->cnt;
@@ -639,6 +436,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
             ConvLdsArgs A;
             memset(&A, 0, sizeof(A));
             A.x = in.x; A.x_bs = (long long)(T + 2 * kHfPad) * u.Ci; A.ldx = u.Ci; A.x_ss = in.ss; A.x_scale = in.scale; A.slope = 0.1f;
+            A.x_row0 = kHfPad; A.x_rows = T + 2 * kHfPad; A.stride = 1;
             A.y = c->U[i]; A.y_bs = (long long)(To + 2 * kHfPad) * u.Co; A.y_off = (long long)kHfPad * u.Co; A.ldy = N;
             A.T = T; A.ntiles = N / 16;
             A.job[0].wp = reinterpret_cast<const float4*>(u.wp); A.job[0].b = u.b; A.job[0].k = u.ntap; A.job[0].dil = 1; A.job[0].row_off = u.dmin;
@@ -674,6 +472,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
             ConvLdsArgs A;
             memset(&A, 0, sizeof(A));
             A.x = c->U[i]; A.x_bs = (long long)(T + 2 * kHfPad) * ch; A.ldx = ch; A.slope = 0.1f; A.x_scale = 1.f;
+            A.x_row0 = kHfPad; A.x_rows = T + 2 * kHfPad; A.stride = 1;
             A.y = c->R[i]; A.y_bs = A.x_bs; A.y_ps = c->plane[i]; A.y_off = (long long)kHfPad * ch; A.ldy = ch;
             A.resid = c->U[i]; A.T = T; A.ntiles = ch / 16;
             for (int j = 0; j < nk; ++j) {

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "gemm.h"
+#include "conv_lds.h"
 #include <algorithm>
 
 namespace gvc {
@@ -65,22 +65,25 @@ static __global__ __launch_bounds__(256) void k_hb_conv0(const float* wav, const
     }
 }
 
-// GroupNorm(C groups over C channels) statistics: per (b, channel) over time; chunks combined in double
-static __global__ void k_hb_gn_stats(const float* part, float* stats, int nchunk, int T0, int C) {
-    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// GroupNorm(C groups over C channels) statistics: per (b, channel) over time; chunks combined in double.
+// A workgroup owns 8 channels; 32 lanes per channel take every 32nd chunk (all their requests in flight at once) and combine with a
+// fixed-order shuffle tree (two workgroups walking the chunks serially took 9 us for a 1 s chunk: 7 dependent round trips).
+static __global__ __launch_bounds__(256) void k_hb_gn_stats(const float* part, float* stats, int nchunk, int T0, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (c >= C) return;                           // (whole 32-lane groups leave together: C % 8 == 0 is not required)
     double s = 0.0, ss = 0.0;
-    // sixteen chunk partials per round trip (one request per loop iteration took 50 dependent-looking trips for a 1 s chunk);
-    // summed in chunk order, as before
-    for (int i0 = 0; i0 < nchunk; i0 += 16) {
-        float2 pv[16];
+    for (int i0 = l; i0 < nchunk; i0 += 32 * 8) {
+        float2 pv[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            pv[u] = *reinterpret_cast<const float2*>(part + (((size_t)b * nchunk + min(i0 + u, nchunk - 1)) * C + c) * 2);
+        for (int u = 0; u < 8; ++u)
+            pv[u] = *reinterpret_cast<const float2*>(part + (((size_t)b * nchunk + min(i0 + 32 * u, nchunk - 1)) * C + c) * 2);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (i0 + u < nchunk) { s += (double)pv[u].x; ss += (double)pv[u].y; }
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 32 * u < nchunk) { s += (double)pv[u].x; ss += (double)pv[u].y; }
     }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 32); ss += __shfl_xor(ss, o, 32); }
+    if (l) return;
     const double mean = s / T0;
     double var = ss / T0 - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -318,6 +321,9 @@ struct gvc_hubert {
     float* conv0_w = nullptr;                     // [C0][k0]
     HbLn gn;
     std::vector<float*> conv_w;                   // layers 1.. : [Co][k*Ci]
+    std::vector<float*> conv_wp;                  // ... and their FM16 copies for k_conv_lds (null: shape not eligible)
+    int conv_lds = 1;                             // GVC_HUBERT_CONV_LDS=0: convs 1.. always on the tiled GEMM
+    int conv_lds_rows = 256;                     // GVC_HUBERT_CONV_LDS_ROWS: layers with more output frames than this stay on the tiled GEMM
     HbLn feat_ln, enc_ln;
     HbLin proj, pos, fin;                         // pos.w: [E][kp*cg]
     std::vector<HbLayer> layers;
@@ -397,6 +403,11 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
             float* w = nullptr;
             rc = hb_alloc(c, &w, (size_t)D.conv_dim[i] * D.conv_kernel[i] * D.conv_dim[i - 1]);
             c->conv_w.push_back(w);
+            float* wp = nullptr;
+            if (!rc && conv_lds_ci_ok(D.conv_dim[i - 1]) && D.conv_dim[i] % 16 == 0 &&
+                conv_lds_bytes(D.conv_dim[i - 1], D.conv_kernel[i], 1, false, D.conv_stride[i]) <= kConvLdsMax)
+                rc = hb_alloc(c, &wp, (size_t)D.conv_dim[i] * D.conv_kernel[i] * D.conv_dim[i - 1]);
+            c->conv_wp.push_back(wp);
         }
     }
     const int Cl = D.conv_dim[D.n_conv - 1];
@@ -440,6 +451,9 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
     if (getenv("GVC_HUBERT_GRAPH")) c->use_graph = atoi(getenv("GVC_HUBERT_GRAPH"));
     if (getenv("GVC_HUBERT_SKINNY")) c->skinny = atoi(getenv("GVC_HUBERT_SKINNY"));
     if (getenv("GVC_HUBERT_STRIP")) c->strip = atoi(getenv("GVC_HUBERT_STRIP"));
+    if (getenv("GVC_HUBERT_CONV_LDS")) c->conv_lds = atoi(getenv("GVC_HUBERT_CONV_LDS"));
+    if (getenv("GVC_HUBERT_CONV_LDS_ROWS")) c->conv_lds_rows = atoi(getenv("GVC_HUBERT_CONV_LDS_ROWS"));
+    conv_lds_init_attributes();
     if (E % 128 != 0 || D.ffn_dim % 128 != 0) c->skinny = 0;
     if (rc) { gvc_hubert_destroy(c); return rc; }
     *out = c;
@@ -487,6 +501,7 @@ extern "C" int gvc_hubert_bind_weight(gvc_hubert* c, const char* name, const flo
                 const int Co = D.conv_dim[i], Ci = D.conv_dim[i - 1], k = D.conv_kernel[i];
                 GVC_REQUIRE(numel == (int64_t)Co * Ci * k, GVC_ERR_ARG, "%s: wrong size", name);
                 hipLaunchKernelGGL(k_hb_repack_conv, dim3(1024), dim3(256), 0, s, src, c->conv_w[i - 1], Co, Ci, k);
+                if (c->conv_wp[i - 1]) hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, c->conv_w[i - 1], c->conv_wp[i - 1], Co, k * Ci);
                 GVC_LAUNCH_CHECK();
             }
         } else if (i == 0 && (ends_with(n, ".2.weight") || ends_with(n, ".2.bias"))) rc = ln(c->gn, D.conv_dim[0]);
@@ -544,7 +559,7 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     int Tin = hb_frames(D, T, 1);
     const int C0 = D.conv_dim[0];
     const int nchunk = cdiv(Tin, kC0Chunk);
-    hipLaunchKernelGGL(k_hb_gn_stats, dim3(cdiv(C0, 256), B), dim3(256), 0, s, c->part, c->stats, nchunk, Tin, C0);
+    hipLaunchKernelGGL(k_hb_gn_stats, dim3(cdiv(C0, 8), B), dim3(256), 0, s, c->part, c->stats, nchunk, Tin, C0);
     GVC_LAUNCH_CHECK();
     {
         const size_t n4 = (size_t)Tin * C0 / 4;
@@ -556,6 +571,22 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     for (int i = 1; i < D.n_conv; ++i) {
         const int Ci = D.conv_dim[i - 1], Co = D.conv_dim[i], k = D.conv_kernel[i], st = D.conv_stride[i];
         const int Tout = (Tin - k) / st + 1;
+        if (c->conv_lds && c->conv_wp[i - 1] && Tout <= c->conv_lds_rows) {
+            // one memory round trip per workgroup (conv_lds.h): the layer is too small for the tiled GEMM's k-loop to pay (1 s chunk: the
+            // last three layers, 13.4 / 9.8 / 9.6 us against 16.4 / 12.5 / 13.5; with more frames the 133 KB input tile per 32 x 16
+            // outputs loses to the GEMM: 68 against 49 us at 1599 frames)
+            ConvLdsArgs A;
+            memset(&A, 0, sizeof(A));
+            A.x = c->act[cur]; A.x_bs = (long long)Tin * Ci; A.ldx = Ci; A.x_scale = 1.f; A.slope = 1.f;
+            A.x_rows = Tin; A.stride = st;
+            A.y = c->act[cur ^ 1]; A.y_bs = (long long)Tout * Co; A.ldy = Co;
+            A.T = Tout; A.ntiles = Co / 16; A.act = ACT_GELU_ERF;
+            A.job[0].wp = reinterpret_cast<const float4*>(c->conv_wp[i - 1]); A.job[0].k = k; A.job[0].dil = 1;
+            if ((rc = launch_conv_lds(Ci, 1, A, 1, B, conv_lds_bytes(Ci, k, 1, false, st), s))) return rc;
+            cur ^= 1;
+            Tin = Tout;
+            continue;
+        }
         GemmArgs G;
         memset(&G, 0, sizeof(G));
         G.A = c->act[cur]; G.lda = st * Ci; G.a_batch_stride = (long long)Tin * Ci;
