@@ -532,6 +532,19 @@ static int hf_post(gvc_hifigan* c, const HfIn& x, int B, int T, float* wav, hipS
     return GVC_OK;
 }
 
+static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int n, int scale, float* wav, hipStream_t s);
+
+// a node of an executable graph refused its new parameters: from now on only the conv chain is replayed from a graph
+static int hf_patch_failed(gvc_hifigan* c, int B, int T0, int head, const float* in, int n, int scale, float* wav, hipStream_t s) {
+    (void)hipGetLastError();
+    for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
+    c->graphs.clear();
+    c->use_graph = 2;
+    hf_head(c, head, in, B, T0, n, scale, s);
+    GVC_LAUNCH_CHECK();
+    return hf_run(c, B, T0, head, in, n, scale, wav, s);
+}
+
 // The whole call is ONE graph per (entry point, B, frames, scale): input staging, the conv chain, conv_post.  The caller's two
 // pointers (input, waveform) are parameters of the first and the last kernel node and are patched in the executable graph when
 // they differ from the previous call's (a stream launch after a graph launch costs an 8 us bubble; a patch is host work).
@@ -550,6 +563,10 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
     const long long key = ((long long)(whole ? head + 1 : 0) << 60) | ((long long)B << 44) | ((long long)(whole ? scale : 0) << 32) | (unsigned)T0;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
+        if (c->graphs.size() >= 64) {          // bounded cache: the frame count of a non-streaming call varies freely
+            for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
+            c->graphs.clear();
+        }
         HfPlan pl;
         GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
         if (whole) hf_head(c, head, in, B, T0, n, scale, c->cap_stream);
@@ -593,7 +610,7 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
         void* a_cf[] = {&in, &x0, &d, &t0};
         kp.func = head == kHeadLatents ? reinterpret_cast<void*>(&k_interp_linear) : reinterpret_cast<void*>(&k_cf_to_time_major);
         kp.kernelParams = head == kHeadLatents ? a_lat : a_cf;
-        GVC_CHECK_HIP(hipGraphExecKernelNodeSetParams(pl.ge, pl.head, &kp));
+        if (hipGraphExecKernelNodeSetParams(pl.ge, pl.head, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
         pl.in = in;
     }
     if (whole && pl.wav != wav) {
@@ -608,7 +625,7 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
         void* a[] = {&x.x, &x.ss, &x.scale, &pw, &pb, &wav, &T, &C, &k, &slope};
         kp.func = x.nsum == 1 ? reinterpret_cast<void*>(&k_conv_post_tanh<1>) : reinterpret_cast<void*>(&k_conv_post_tanh<3>);
         kp.kernelParams = a;
-        GVC_CHECK_HIP(hipGraphExecKernelNodeSetParams(pl.ge, pl.post, &kp));
+        if (hipGraphExecKernelNodeSetParams(pl.ge, pl.post, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
         pl.wav = wav;
     }
     GVC_CHECK_HIP(hipGraphLaunch(pl.ge, s));

@@ -163,6 +163,24 @@ def test_long_latent_sequences_are_vocoded_in_windows():
     np.testing.assert_allclose(v(mel.to(DEV)).cpu().numpy(), exp.numpy(), atol=1e-4)
 
 
+def test_long_latent_sequences_full_size_vocoder_windows():
+    """the same at the trained generator's size (ResBlock planes, K-split conv_pre, 64-frame tiles): 3+ windows of 64 frames with the
+    overlap `window_overlap` derives from the config, against the one-shot oracle"""
+    from genvc_amd.layers.hifigan import HiFiGAN
+    from oracle import genvc_oracle as O
+    c = gcfg.DEFAULT_VOCODER
+    v = HiFiGAN(c["input_feat_dim"], c["upsample_initial_channel"], c["resblock_kernel_sizes"], c["resblock_dilation_sizes"],
+                c["upsample_rates"], c["upsample_kernel_sizes"], resblock_type="2")
+    w = synth.make_weights(14, synth.hifigan_weight_spec(c))
+    v.load_state_dict(w)
+    v.to(DEV).bind(max_batch=1, max_frames=128)
+    lat = synth.uniform(14, "long_full", (1, 45, c["input_feat_dim"]), 1.0)           # 180 frames
+    got = v.forward_latents(lat.to(DEV), 4)
+    exp = O.vocode_latents(w, c, lat)
+    assert got.shape == exp.shape == (1, 1, 45 * 1024)
+    np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), atol=1e-4)
+
+
 def test_harness_streaming_and_offline_agree():
     from genvc_amd.inference.inference_utils import synthesize_utt, synthesize_utt_streaming
     from genvc_amd.parallel_offline import convert_offline
