@@ -916,9 +916,21 @@ extern "C" int gvc_gemm_probe(int32_t variant, const float* A, const float* W, c
         hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, W, Wf, N, K);
         G.A = Af; G.lda = K; G.Wt = Wf; G.ldw = K;
     }
+    // GVC_PROBE_COLD=n (skinny): n copies of the weights, a different one per launch (n x N x K x 4 bytes beyond the 256 MB memory-side
+    // cache = weights from HBM, as in a layer stack: 3-4 us more than the warm loop at 48 rows)
+    const int ncold = variant == 2 && getenv("GVC_PROBE_COLD") ? atoi(getenv("GVC_PROBE_COLD")) : 0;
+    float* Wcold = nullptr;
+    struct ColdFree { float** p; ~ColdFree() { if (*p) (void)hipFree(*p); } } cold_free{&Wcold};
+    if (ncold > 0) {
+        GVC_CHECK_HIP(hipMalloc((void**)&Wcold, (size_t)ncold * N * K * sizeof(float)));
+        for (int i = 0; i < ncold; ++i)
+            GVC_CHECK_HIP(hipMemcpyAsync(Wcold + (size_t)i * N * K, Wf, (size_t)N * K * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    int it_no = 0;
     auto once = [&]() -> int {
         if (variant == 0) return launch_gemm_cap(G, 1, work_cap, s);
         if (variant == 1) return launch_gemm_strip(G, sk_max, work_cap, 0, nullptr, s);
+        if (ncold > 0) G.Wt = Wcold + (size_t)(it_no++ % ncold) * N * K;
         return launch_gemm_skinny(G, 1, work_cap, s);
     };
     int rc = once();

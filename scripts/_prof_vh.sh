@@ -1,7 +1,5 @@
-export TMPDIR=/tmp
-R=$PWD
-python -m pytest tests/test_gpu_shell.py -x -q -m gpu -k "vocod" 2>&1 | tail -3
-python scripts/time_prefill.py 1 13; python scripts/time_prefill.py 1 75
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_pf -o pf --output-format csv -- python $R/scripts/time_prefill.py 1 13 > /dev/null 2>&1
-cd $R
+for cold in 0 64; do for touch in 0 1; do
+ echo "== cold=$cold touch=$touch"; GVC_PROBE_COLD=$cold GVC_PROBE_TOUCH=$touch python scripts/time_gemm.py 48 110 2>&1 | grep "^M=" | sed 's/tiled.*skinny/skinny/'
+done; done
+echo "== cold=64 SK=4 (mlp c_proj as shipped)"; GVC_PROBE_COLD=64 GVC_PROBE_SK=4 python scripts/time_gemm.py 48 2>&1 | grep "^M=" | sed 's/tiled.*skinny/skinny/'
+echo "== cold=64 SK=4 touch"; GVC_PROBE_COLD=64 GVC_PROBE_SK=4 GVC_PROBE_TOUCH=1 python scripts/time_gemm.py 48 2>&1 | grep "^M=" | sed 's/tiled.*skinny/skinny/'
