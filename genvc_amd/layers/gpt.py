@@ -205,9 +205,20 @@ class GPT(nn.Module):
         independent, so with deterministic decoding (top_k = 1) every group's result is what generate() returns for it (bit for
         bit when both land on the same decode kernels, i.e. the rows path from 5 streams up; within float rounding otherwise);
         with sampling the per-row random streams would be numbered differently, so that case runs the groups one after another.
+        `max_new_tokens` may be a list with one budget per group (benchmark mode: synthetic weights seldom stop, SURVEY.md 8d fixes
+        the tokens of a segment by its duration): a group whose budget is spent leaves the joint decode, and the steps that remain
+        run over the live streams only (fewer rows per step: the 8-row instead of the 16-row one-launch step for configs[2]'s tail).
         Returns a list of int64 [B_i, n_i] (reference gpt.py:594-609 per group)."""
         self._need_engine()
         kw = dict(generate_kwargs)
+        budgets = kw.get("max_new_tokens")
+        if isinstance(budgets, (list, tuple)):
+            if len(budgets) != len(groups):
+                raise ValueError(f"generate_groups: {len(budgets)} token budgets for {len(groups)} groups")
+            budgets = [int(b) for b in budgets]
+            kw["max_new_tokens"] = max(budgets)
+        else:
+            budgets = None
         greedy = kw.get("top_k", 0) == 1 or not kw.get("do_sample", True)
         total = sum(int(t.shape[0]) for _, t in groups)
         stats = getattr(self, "groups_stats", None)        # {"joint": n, "separate": n}: bench.py / tests count the two paths
@@ -221,6 +232,8 @@ class GPT(nn.Module):
                 kg = dict(kw)
                 if not greedy:
                     kg["seed"] = int(kw.get("seed", 0)) + 7919 * gi
+                if budgets is not None:
+                    kg["max_new_tokens"] = budgets[gi]
                 outs.append(self.generate(c, t, **kg))
             self.last_latents = None      # (same contract as the joint path: callers of generate_groups want tokens)
             return outs
@@ -229,6 +242,10 @@ class GPT(nn.Module):
         group = kw.pop("group", 16)
         dev = groups[0][1].device
         max_new = kw.get("max_new_tokens") or self.max_gen_mel_tokens
+        # rows in order of falling budget: the live streams are always the first rows of every buffer
+        order = sorted(range(len(groups)), key=lambda i: -(budgets[i] if budgets else max_new))
+        groups = [groups[i] for i in order]
+        gb = [budgets[i] if budgets else max_new for i in order]
         prefixes = [self.engine.prefix_embeddings(c.to(torch.float32).contiguous(), t.to(torch.int32).contiguous()) for c, t in groups]
         n0s = [int(p.shape[1]) + 1 for p in prefixes]
         width = max(n0s) + max_new + 8
@@ -252,17 +269,20 @@ class GPT(nn.Module):
         params = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
         done = 0
         while done < max_new:
-            n = min(group, max_new - done)
-            self.engine.generate(slots, ids, ids_len, finished, params, done, n, toks, lats, max_keys=max(n0s) + done + n)
+            live_groups = [g for g in range(len(groups)) if gb[g] > done]
+            live = spans[live_groups[-1]][1]                                   # rows [0, live) still have tokens to produce
+            n = min(group, min(gb[g] for g in live_groups) - done)              # (a call never crosses the end of a budget)
+            self.engine.generate(slots[:live], ids[:live], ids_len[:live], finished[:live], params, done, n, toks[:live], lats[:live],
+                                 max_keys=max(n0s[g] for g in live_groups) + done + n)
             done += n
-            stop = bool(finished.all().item())
+            stop = bool(finished[:live].all().item())
             self.engine.health()
             if stop:
                 break
-        out = []
-        for lo, hi in spans:
-            t = toks[lo:hi, :done].long()
-            out.append(t[:, :self._stop_len(t)])
+        out = [None] * len(groups)
+        for g, (lo, hi) in enumerate(spans):
+            t = toks[lo:hi, :min(done, gb[g])].long()
+            out[order[g]] = t[:, :self._stop_len(t)]
         self.last_latents = None          # (per-group latents are not kept: the callers of this path want tokens)
         return out
 

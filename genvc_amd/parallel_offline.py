@@ -51,13 +51,16 @@ def _n_segments(n_samples, seg):
 
 
 @torch.inference_mode()
-def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg=None, **gen_kwargs):
+def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg=None, tokens_per_second=None, **gen_kwargs):
     """Tokens of a micro-batch of utterances.  Segment s of the utterances that HAVE a segment s of the same length forms
     one class (same prefix length: all full segments of the batch, and equal-length tails), prefilled in one batched call;
     tails of other lengths are classes of their own -- never padded, which would change the reference's result
     (inference_utils.py:43-50).  With greedy decoding (top_k = 1, the configuration BASELINE configs[2] names) the classes are
     then decoded TOGETHER, as many per joint decode as the context has KV slots; a sampling run (top_k > 1) decodes one class
     after another, each with its own random stream (layers/gpt.py generate_groups).
+    tokens_per_second (benchmark mode, SURVEY.md 8d: synthetic weights seldom emit the stop token): a class of segments of t seconds
+    gets the fixed budget round(t * tokens_per_second) instead of max_new_tokens (23.4375: 141 tokens for 6 s, 94 for 4 s); a class
+    whose budget is spent leaves the joint decode.
     Returns int32 [B, n_seg, max_len] padded with the stop token (also the rows of segments an utterance does not have)."""
     m = model
     stop = m.gpt.stop_audio_token
@@ -78,11 +81,11 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
         for b, p in enumerate(per_utt):
             if s < len(p):
                 groups.setdefault(p[s].shape[-1], []).append(b)
-        for _, rows in sorted(groups.items(), reverse=True):
+        for n_samples, rows in sorted(groups.items(), reverse=True):
             wav = torch.cat([per_utt[b][s] for b in rows], 0)
             feat = m.content_extractor.extract_content_features(wav)
             codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
-            classes.append((s, rows, codes))
+            classes.append((s, rows, codes, n_samples))
     max_slots = getattr(m.gpt, "max_slots", 8)
     i = 0
     while i < len(classes):                  # as many classes per joint decode as the KV slots hold
@@ -91,8 +94,12 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
             n += len(classes[j][1])
             j += 1
         j = max(j, i + 1)
-        gens = m.gpt.generate_groups([(cond_latent.expand(len(rows), -1, -1).contiguous(), codes) for _, rows, codes in classes[i:j]], **kw)
-        for (s, rows, _), gen in zip(classes[i:j], gens):
+        kj = dict(kw)
+        if tokens_per_second:
+            cap = kw.get("max_new_tokens") or max_len
+            kj["max_new_tokens"] = [max(1, min(cap, int(round(ns / m.content_sample_rate * tokens_per_second)))) for _, _, _, ns in classes[i:j]]
+        gens = m.gpt.generate_groups([(cond_latent.expand(len(rows), -1, -1).contiguous(), codes) for _, rows, codes, _ in classes[i:j]], **kj)
+        for (s, rows, _, _), gen in zip(classes[i:j], gens):
             out[rows, s, :gen.shape[1]] = gen.to(torch.int32)
         i = j
     return out

@@ -410,6 +410,12 @@ def test_generate_groups_equals_separate_generate_calls():
     sep = [m.gpt.generate(c, t, **kw) for c, t in groups]
     for a, b in zip(joint, sep):
         assert torch.equal(a, b), (a, b)
+    # one token budget per class (benchmark mode): the class whose budget is spent leaves the joint decode and the
+    # remaining steps run over the live streams only; every class still gets its own generate() result, in the caller's order
+    for budgets in ([12, 20], [20, 7], [9, 9]):
+        joint_b = m.gpt.generate_groups(groups, **dict(kw, max_new_tokens=budgets))
+        for (c, t), a, nb in zip(groups, joint_b, budgets):
+            assert a.shape[1] <= nb and torch.equal(a, m.gpt.generate(c, t, **dict(kw, max_new_tokens=nb)))
     # sampling: the groups run one after another, each class with its own random stream (seed + 7919 * class index: with one shared
     # seed every class would draw the same per-row sequences), the rows of a class keeping the counter RNG's per-row numbering
     kw_s = dict(kw, top_k=15, seed=7)
@@ -427,6 +433,10 @@ def test_generate_groups_equals_separate_generate_calls():
     finally:
         m.gpt.generate_groups = joint_fn
     assert both.shape == ref.shape and both.shape[:2] == (6, 2) and torch.equal(both, ref)
+    # ... and with budgets by segment duration: 2 s -> 16 tokens, 0.5 s -> 4
+    timed = convert_batch(m, wavs, cond, seg_len=2.0, max_new_tokens=16, tokens_per_second=8.0)
+    stop = m.gpt.stop_audio_token
+    assert torch.equal(timed[:, 0], both[:, 0]) and torch.equal(timed[:, 1, :4], both[:, 1, :4]) and bool((timed[:, 1, 4:] == stop).all())
 
 
 def test_stream_sessions_left_context_contentvec():
