@@ -1,4 +1,7 @@
-for cold in 0 64; do
- echo "== cold=$cold"; GVC_PROBE_COLD=$cold python scripts/time_gemm.py 48 110 2>&1 | grep "^M=" | sed 's/tiled.*skinny/skinny/'
-done
-python scripts/time_prefill.py 1 13; python scripts/time_prefill.py 1 75; python scripts/time_hubert.py 16000 1
+export TMPDIR=/tmp
+R=$PWD
+mkdir -p $R/gpurun_out/prof_stream
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stream -o st --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-offline --no-harness > $R/gpurun_out/prof_stream/bench.json 2>/dev/null
+cd $R
+tail -c 300 gpurun_out/prof_stream/bench.json
