@@ -126,6 +126,12 @@ int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
         if (SK > max_by_k) SK = max_by_k;
         if (SK > 16) SK = 16;
         while (SK > 1 && (long long)batch * SK * G.M * G.N > work_cap) --SK;
+    } else if (tiles < 2 * sk_tiles && G.K >= 64 * BK && G.work) {
+        // about one workgroup per CU and a long K (ContentVec's positional conv on an utterance: 128 tiles x 192 k steps): the
+        // k-loop is latency-bound at one workgroup per CU, 183 us; three or four per CU overlap their round trips
+        SK = (int)((4 * sk_tiles + tiles - 1) / tiles);
+        if (SK > G.K / (16 * BK)) SK = G.K / (16 * BK);
+        while (SK > 1 && (long long)batch * SK * G.M * G.N > work_cap) --SK;
     }
     G.SK = SK;
     dim3 grid(tn, tm, batch * SK);
