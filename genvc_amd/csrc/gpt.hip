@@ -1227,14 +1227,14 @@ extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, cons
 // ---------------------------------------------------------------------------------------------
 // generation loop: one captured graph = [sample -> decode step] for a fixed B, replayed n_steps times
 // ---------------------------------------------------------------------------------------------
-static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, int n_unroll, hipGraphExec_t* out) {
+static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, int n_unroll, bool greedy, hipGraphExec_t* out) {
     hipStream_t cs = c->cap_stream;
     int rc = GVC_OK;
     GVC_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     // n_unroll consecutive steps in ONE graph: the boundary between two graph launches costs several times the boundary between
     // two kernels of a graph, and the host looks at the finished flags once per group of steps anyway
     for (int u = 0; u < n_unroll && rc == GVC_OK; ++u) {
-    rc = launch_sample_indirect(&c->gen_call->sc, B, cs);
+    rc = launch_sample_indirect(&c->gen_call->sc, B, greedy, cs);
     if (rc == GVC_OK && persist_ok(c, B))
         rc = launch_persist(c, c->gen_call->slots, c->tok_buf, c->logits, c->latent, c->step_ctr, cs);
     else if (rc == GVC_OK && rows_decode_ok(c, B))
@@ -1298,12 +1298,14 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     c->last_variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1)));
     // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
     static const int kStepUnroll = getenv("GVC_STEP_UNROLL") ? std::max(1, atoi(getenv("GVC_STEP_UNROLL"))) : 8;
+    // (the sampler kernel is chosen at capture time: a graph serves top_k = 1 or everything else)
+    const bool greedy = sample_greedy_ok(p->top_k, c->dm.d_model);
     auto graph_of = [&](int unroll, hipGraphExec_t* ge) -> int {
-        const int k = key + (unroll > 1 ? (1 << 24) * unroll : 0);
+        const int k = key + (unroll > 1 ? (1 << 24) * unroll : 0) + (greedy ? (1 << 30) : 0);
         auto it = c->graphs.find(k);
         if (it == c->graphs.end()) {
             hipGraphExec_t g1;
-            int r = build_step_graph(c, B, fused, key_chunks, unroll, &g1);
+            int r = build_step_graph(c, B, fused, key_chunks, unroll, greedy, &g1);
             if (r) return r;
             it = c->graphs.emplace(k, g1).first;
         }
