@@ -13,7 +13,7 @@ m.config.top_k = 1
 srcs = [synth.synth_audio(500 + i, "src", 160000) for i in range(8)]
 ref = synth.synth_audio(7, "ref", 72000)
 cond = m.get_gpt_cond_latents(ref.to(m.device), 24000)
-kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141)
+kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141, tokens_per_second=23.4375)
 convert_batch(m, srcs, cond, **kw)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); convert_batch(m, srcs, cond, **kw); torch.cuda.synchronize(); whole = time.perf_counter() - t0
@@ -31,7 +31,7 @@ for s in range(2):
     codes, out[f"dvae_{s}"] = T(lambda: m.content_dvae.get_codebook_indices(feat.transpose(1, 2)))
     groups.append((cond.expand(8, -1, -1).contiguous(), codes))
 g = m.gpt
-k2 = dict(_sampling_kwargs(m)); k2.update(top_k=1, max_new_tokens=141)
+k2 = dict(_sampling_kwargs(m)); k2.update(top_k=1, max_new_tokens=[141, 94])
 eng = g.engine
 prefixes = []
 for i, (c, t) in enumerate(groups):
@@ -44,4 +44,4 @@ _, out["generate_groups_total"] = T(lambda: g.generate_groups(groups, **k2))
 print(f"convert_batch of 8 utterances: {whole * 1e3:.1f} ms  ->  {8 / whole:.1f} utterances/s")
 for k, v in out.items():
     print(f"  {k:28s} {v:8.2f} ms")
-print(f"  decode inside generate_groups ~ {out['generate_groups_total'] - sum(v for k, v in out.items() if k.startswith(('prefix_', 'prefill_'))):.1f} ms for 141 steps")
+print(f"  decode inside generate_groups ~ {out['generate_groups_total'] - sum(v for k, v in out.items() if k.startswith(('prefix_', 'prefill_'))):.1f} ms for 94 steps x 16 streams + 47 steps x 8 streams")
