@@ -178,9 +178,29 @@ struct GenCall {
     int32_t slots[64];
 };
 
-__global__ void k_set_gen_call(GenCall* dst, SampleCall sc, const int32_t* slots, int B) {
-    if (threadIdx.x == 0) dst->sc = sc;
-    if (threadIdx.x < B) dst->slots[threadIdx.x] = slots[threadIdx.x];
+// Start / end of a gvc_gpt_generate call in ONE launch each (they used to be a memset, k_set_gen_call and two k_stage_rows before the
+// step graphs and two k_stage_rows after them: six 4-5 us operations around every group of eight streaming steps).
+// begin: workgroup b < B un-parks the next-step logits and latent of stream b; workgroup B resets the step counter and stores the
+// call parameters.  end: workgroup b parks them again.
+__global__ void k_gen_begin(GenCall* dst, SampleCall sc, const int32_t* slots, int B, int32_t* step_ctr, float* logits, float* slot_logits,
+                            int vocab, float* latent, float* slot_latent, int d) {
+    const int b = blockIdx.x;
+    if (b == B) {
+        if (threadIdx.x == 0) { dst->sc = sc; *step_ctr = 0; }
+        if (threadIdx.x < B) dst->slots[threadIdx.x] = slots[threadIdx.x];
+        return;
+    }
+    const size_t sl = (size_t)slots[b];
+    for (int i = threadIdx.x; i < vocab; i += blockDim.x) logits[(size_t)b * vocab + i] = slot_logits[sl * vocab + i];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) latent[(size_t)b * d + i] = slot_latent[sl * d + i];
+}
+
+__global__ void k_gen_end(const int32_t* slots, const float* logits, float* slot_logits, int vocab, const float* latent, float* slot_latent,
+                          int d) {
+    const int b = blockIdx.x;
+    const size_t sl = (size_t)slots[b];
+    for (int i = threadIdx.x; i < vocab; i += blockDim.x) slot_logits[sl * vocab + i] = logits[(size_t)b * vocab + i];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) slot_latent[sl * d + i] = latent[(size_t)b * d + i];
 }
 
 }  // namespace gvc
@@ -1279,10 +1299,8 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     sc.finished = finished; sc.p = *p; sc.step = 0; sc.step_ptr = c->step_ctr; sc.tok_out = c->tok_buf;
     sc.tokens_out = tokens_out; sc.tok_stride = tok_stride; sc.i0 = i0; sc.latent_src = c->latent;
     sc.latents_out = latents_out; sc.lat_stride = lat_stride; sc.d = c->dm.d_model;
-    GVC_CHECK_HIP(hipMemsetAsync(c->step_ctr, 0, sizeof(int32_t), s));
-    hipLaunchKernelGGL(k_set_gen_call, dim3(1), dim3(64), 0, s, c->gen_call, sc, slots, B);
-    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 0);
-    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 0);
+    hipLaunchKernelGGL(k_gen_begin, dim3(B + 1), dim3(256), 0, s, c->gen_call, sc, slots, B, c->step_ctr, c->logits, c->slot_logits,
+                       c->dm.vocab, c->latent, c->slot_latent, c->dm.d_model);
     GVC_LAUNCH_CHECK();
     const bool fused = fused_ok(c, B, key_bound);
     // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
@@ -1323,8 +1341,8 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
         if ((rc = graph_of(1, &ge))) return rc;
         for (; left > 0; --left) GVC_CHECK_HIP(hipGraphLaunch(ge, s));
     }
-    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->logits, c->slot_logits, slots, c->dm.vocab, 1);
-    hipLaunchKernelGGL(k_stage_rows, dim3(B), dim3(256), 0, s, c->latent, c->slot_latent, slots, c->dm.d_model, 1);
+    hipLaunchKernelGGL(k_gen_end, dim3(B), dim3(256), 0, s, slots, c->logits, c->slot_logits, c->dm.vocab, c->latent, c->slot_latent,
+                       c->dm.d_model);
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
