@@ -24,6 +24,12 @@ namespace gvc {
 // one resident at once), 32 otherwise
 __host__ __device__ constexpr int conv_lds_mt(int ci, bool split) { return (ci <= 64 && !split) ? 4 : 2; }
 
+__device__ __forceinline__ float conv_lds_act(float v, int act) {
+    if (act == ACT_GELU_ERF) return gelu_erf(v);
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
 struct ConvLdsJob {
     const float4* wp;                    // FM16 copy of [N][k*CI]
     const float* b;                      // [N]
@@ -41,10 +47,10 @@ struct ConvLdsArgs {
     int T, ntiles;                                   // output frames, N / 16
     int ldx;                                         // floats between input rows (CI, or more when the jobs are channel slices)
     int x_row0, x_rows, stride;                      // first input row of frame 0 (the padding of a padded buffer), rows per batch element, conv stride
-    int act;                                         // GemmAct applied after bias and residual (ACT_NONE / ACT_GELU_ERF)
+    int act;                                         // GemmAct applied after bias and residual (ACT_NONE / ACT_RELU / ACT_GELU_ERF)
     // SPLIT (conv_pre: few outputs, K = 7 * 1024): job j < split is the channel slice [j*CI, (j+1)*CI) of every tap -- x_ps = CI, weights
     // job[0].wp + j*wp_js -- and writes RAW partial sums to plane j of y; the last workgroup to finish a tile (cnt) adds the
-    // planes in order, adds the bias and writes yf[b*yf_bs + yf_off + t*ldy + n]
+    // planes in order, adds the bias (and resid, indexed like yf), applies act and writes yf[b*yf_bs + yf_off + t*ldy + n]
     int split; long long wp_js; int* cnt;
     float* yf; long long yf_bs, yf_off;
     ConvLdsJob job[3];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_lds(const ConvLdsArgs A) {
         if constexpr (!SPLIT) {
             v += bn;
             if (A.resid) v += r1[rr];
-            if (A.act == ACT_GELU_ERF) v = gelu_erf(v);
+            v = conv_lds_act(v, A.act);
         }
         if (t0 + m < A.T) {
             float* dst = A.y + ob + (size_t)jb * A.y_ps + (size_t)(t0 + m) * A.ldy;
@@ -184,9 +190,36 @@ __global__ __launch_bounds__(NW * 64) void k_conv_lds(const ConvLdsArgs A) {
             const float* pp = A.y + ob + (size_t)(t0 + m) * A.ldy;
             float v = 0.f;
             for (int p = 0; p < A.split; ++p) v += __hip_atomic_load(pp + (size_t)p * A.y_ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.yf[(size_t)b * A.yf_bs + A.yf_off + (size_t)(t0 + m) * A.ldy + n] = v + bn;
+            const size_t o = (size_t)b * A.yf_bs + A.yf_off + (size_t)(t0 + m) * A.ldy + n;
+            v += bn;
+            if (A.resid) v += A.resid[o];              // (SPLIT: the residual is indexed like yf and may BE yf: one thread reads and writes an element)
+            A.yf[o] = conv_lds_act(v, A.act);
         }
     }
+}
+
+// conv weights [Co][Ci][k] (the reference's layout) -> per channel slice s (CS channels) the FM16 copy of [Co][k*CS] (column tap*CS + c):
+// [Ci/CS][FM16].  CS = Ci: the one FM16 matrix of an unsplit conv.
+static __global__ void k_conv_pack_slices(const float* w, float* out, int Co, int Ci, int k, int CS) {
+    const int K = k * CS;
+    const size_t per = (size_t)Co * K, n4 = per * (Ci / CS) / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int sl = (int)(i * 4 / per);
+        const size_t r = i * 4 - (size_t)sl * per;
+        const int n = (int)(r / K), kc = (int)(r % K), tap = kc / CS, cl = kc % CS;
+        const float* src = w + ((size_t)n * Ci + sl * CS + cl) * k + tap;
+        *reinterpret_cast<float4*>(out + (size_t)sl * per + fm16_index(n, kc, K)) = make_float4(src[0], src[k], src[2 * k], src[3 * k]);
+    }
+}
+
+// K-split launch (k_conv_lds<CS, 8, 1, true>): A.split channel slices of CS = 64 or 256 channels, partial sums in A.y, result in A.yf
+static inline int launch_conv_lds_split(int cs, const ConvLdsArgs& A, int B, size_t lds, hipStream_t s) {
+    const dim3 grid(cdiv(A.T, 32), A.split * A.ntiles, B);
+    if (cs == 64) hipLaunchKernelGGL((k_conv_lds<64, 8, 1, true>), grid, dim3(512), lds, s, A);
+    else if (cs == 256) hipLaunchKernelGGL((k_conv_lds<256, 8, 1, true>), grid, dim3(512), lds, s, A);
+    else return GVC_ERR_UNSUPPORTED;
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
 }
 
 // LDS bytes of k_conv_lds: the input rows, later the reduction buffer
@@ -207,6 +240,8 @@ static inline void conv_lds_init_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<CI, NW, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     GVC_CONV_LDS_FOR_EACH(GVC_CL_ATTR)
 #undef GVC_CL_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<64, 8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<256, 8, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
 }
 

@@ -1,6 +1,8 @@
 // Content tokenizer: DiscreteVAE.get_codebook_indices (reference layers/dvae.py:324-331) = 1-D conv
 // encoder (:252-291, ResBlock :172-184) + nearest-codebook search (Quantize.forward :87-93).
 //
+// Streaming-sized calls (B x T <= 600 frames: 124 instead of 168 us for a 1 s chunk) run every conv on the one-round-trip kernel of
+// conv_lds.h in 256-channel slices (the last workgroup to arrive adds the slices, bias, skip and ReLU); larger calls:
 // Activations are kept time-major [B][T + 2*pad][C] with zero rows at both ends, so a k-tap conv with
 // stride s is ONE fp32 MFMA GEMM whose A rows are overlapping windows of that buffer
 // (row t = &x[s*t][0], length k*C, lda = s*C) against weights repacked to [C_out][k*C_in]:
@@ -11,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "gemm.h"
+#include "conv_lds.h"
 
 namespace gvc {
 
@@ -128,7 +130,9 @@ __global__ __launch_bounds__(kVqThreads) void k_vq_argmin(const float* x, const 
 
 using namespace gvc;
 
-struct ConvW { float* w = nullptr; float* b = nullptr; int Co = 0, Ci = 0, k = 0; };
+struct ConvW { float* w = nullptr; float* b = nullptr; float* wp = nullptr; int Co = 0, Ci = 0, k = 0; };     // wp: 256-channel slices in FM16 (k_conv_lds)
+
+constexpr int kDvSlice = 256, kDvCounters = 4096;
 
 struct gvc_dvae {
     gvc_dvae_dims dm;
@@ -142,6 +146,13 @@ struct gvc_dvae {
     float *buf[3] = {nullptr, nullptr, nullptr};   // padded time-major activations (ping-pong + residual temp)
     float *enc = nullptr, *work = nullptr;
     long long work_cap = 0;
+    // one-round-trip conv path (conv_lds.h; every conv's input channels a multiple of 256, as at the reference size): every conv
+    // output has its own buffer, so the zero rows either side of the live region are never written (no k_zero_pad_rows launches)
+    bool lds_path = false;               // GVC_DVAE_CONV_LDS=0: the tiled GEMM for every conv
+    int lds_rows = 600;                  // GVC_DVAE_CONV_LDS_ROWS: calls with more than this many input frames (B x T) stay on the tiled GEMM
+    std::vector<float*> lbuf;            // [num_layers] stage outputs (the last one is updated in place by the ResBlocks) + 2 ResBlock temporaries
+    int* cnt = nullptr;                  // arrival counters of the K-split convs
+    int cur_T = -1, cur_B = -1;
     std::vector<void*> allocs;
 };
 
@@ -188,6 +199,35 @@ extern "C" int gvc_dvae_create(const gvc_dvae_dims* dims, gvc_dvae** out) {
     if (!rc) rc = dalloc(c, &c->enc, (size_t)D.max_batch * D.max_frames * D.codebook_dim);
     c->work_cap = 4ll << 20;
     if (!rc) rc = dalloc(c, &c->work, (size_t)c->work_cap);
+    // the k_conv_lds path: every conv in 256-channel slices
+    c->lds_path = !(getenv("GVC_DVAE_CONV_LDS") && atoi(getenv("GVC_DVAE_CONV_LDS")) == 0);
+    if (getenv("GVC_DVAE_CONV_LDS_ROWS")) c->lds_rows = atoi(getenv("GVC_DVAE_CONV_LDS_ROWS"));
+    {
+        std::vector<ConvW*> all;
+        for (ConvW& w : c->down) all.push_back(&w);
+        for (ConvW& w : c->res) all.push_back(&w);
+        all.push_back(&c->last);
+        for (ConvW* w : all) c->lds_path = c->lds_path && w->Ci % kDvSlice == 0 && w->Co % 16 == 0 && conv_lds_bytes(kDvSlice, w->k, 1, true, 2) <= kConvLdsMax;
+        if (c->lds_path) {
+            for (ConvW* w : all)
+                if (!rc) rc = dalloc(c, &w->wp, (size_t)w->Co * w->Ci * w->k);
+            size_t T = D.max_frames;
+            for (int i = 0; i < D.num_layers && !rc; ++i) {
+                T = (T + 1) / 2 + 1;         // (an upper bound of the stage's frames)
+                float* p = nullptr;
+                rc = dalloc(c, &p, (size_t)D.max_batch * (T + 2 * c->pad) * c->down[i].Co);
+                c->lbuf.push_back(p);
+            }
+            for (int i = 0; i < 2 && !rc; ++i) {
+                float* p = nullptr;
+                rc = dalloc(c, &p, (size_t)D.max_batch * (T + 2 * c->pad) * c->inner);
+                c->lbuf.push_back(p);
+            }
+            if (!rc) rc = dalloc(c, reinterpret_cast<float**>(&c->cnt), kDvCounters);
+            if (!rc && hipMemset(c->cnt, 0, kDvCounters * sizeof(int)) != hipSuccess) rc = GVC_ERR_HIP;
+            conv_lds_init_attributes();
+        }
+    }
     if (rc) { gvc_dvae_destroy(c); return rc; }
     *out = c;
     return GVC_OK;
@@ -210,6 +250,10 @@ static int bind_conv(ConvW& w, bool is_bias, const float* src, int64_t numel, co
                 (long long)w.Co * w.Ci * w.k, (long long)numel);
     hipLaunchKernelGGL(k_repack_conv, dim3(1024), dim3(256), 0, s, src, w.w, w.Co, w.Ci, w.k);
     GVC_LAUNCH_CHECK();
+    if (w.wp) {
+        hipLaunchKernelGGL(k_conv_pack_slices, dim3(512), dim3(256), 0, s, src, w.wp, w.Co, w.Ci, w.k, kDvSlice);
+        GVC_LAUNCH_CHECK();
+    }
     return GVC_OK;
 }
 
@@ -277,6 +321,33 @@ static int conv_gemm(gvc_dvae* c, const ConvW& w, const float* src, int Tin, int
     return launch_gemm_cap(G, B, c->work_cap, s);
 }
 
+// the same conv on k_conv_lds: Ci / 256 channel slices x Co / 16 column tiles, slices combined by the last workgroup to arrive
+// (one slice: the plain kernel).  src / dst / skip as in conv_gemm (skip: a padded buffer with the layout of dst, may be dst);
+// dst_padded = false: dst is [B][To][Co] without padding rows
+static int conv_lds(gvc_dvae* c, const ConvW& w, const float* src, int Tin, int stride, float* dst, int To, int B, int act,
+                    const float* skip, bool dst_padded, hipStream_t s) {
+    const int pad = c->pad, nsplit = w.Ci / kDvSlice, tiles = w.Co / 16;
+    ConvLdsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.x = src; A.x_bs = (long long)(Tin + 2 * pad) * w.Ci; A.ldx = w.Ci; A.x_scale = 1.f; A.slope = 1.f;
+    A.x_row0 = pad; A.x_rows = Tin + 2 * pad; A.stride = stride;
+    A.T = To; A.ntiles = tiles; A.ldy = w.Co; A.act = act;
+    A.job[0].wp = reinterpret_cast<const float4*>(w.wp); A.job[0].b = w.b; A.job[0].k = w.k; A.job[0].dil = 1;
+    A.job[0].row_off = -((w.k - 1) / 2);
+    const long long o_bs = dst_padded ? (long long)(To + 2 * pad) * w.Co : (long long)To * w.Co, o_off = dst_padded ? (long long)pad * w.Co : 0;
+    const size_t lds = conv_lds_bytes(kDvSlice, w.k, 1, nsplit > 1, stride);
+    if (nsplit == 1) {
+        A.y = dst; A.y_bs = o_bs; A.y_off = o_off; A.resid = skip;
+        return launch_conv_lds(kDvSlice, 1, A, 1, B, lds, s);
+    }
+    GVC_REQUIRE((long long)nsplit * B * To * w.Co <= c->work_cap && B * cdiv(To, 32) * tiles <= kDvCounters, GVC_ERR_ARG,
+                "dvae: B=%d frames=%d exceed the K-split work buffer", B, To);
+    A.x_ps = kDvSlice; A.split = nsplit; A.wp_js = (long long)tiles * w.k * (kDvSlice / 16) * 64; A.cnt = c->cnt;
+    A.y = c->work; A.y_bs = (long long)To * w.Co; A.y_ps = (long long)B * To * w.Co;
+    A.yf = dst; A.yf_bs = o_bs; A.yf_off = o_off; A.resid = skip;
+    return launch_conv_lds_split(kDvSlice, A, B, lds, s);
+}
+
 static int zero_pads(gvc_dvae* c, float* buf, int C, int T, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_zero_pad_rows, dim3(cdiv(2 * c->pad * C, 256), B), dim3(256), 0, s, buf, C, T, c->pad);
     GVC_LAUNCH_CHECK();
@@ -324,6 +395,41 @@ static int dvae_run(gvc_dvae* c, int B, int T, int32_t* codes_out, float* enc_ou
     int rc;
     float *cur = c->buf[0], *nxt = c->buf[1], *tmp = c->buf[2];
     int C = c->dm.channels, Tc = T;
+    if (c->lds_path && B * T <= c->lds_rows) {
+        if (T != c->cur_T || B != c->cur_B) {
+            // the zero rows around the live regions depend on the geometry: everything is cleared when it changes (the input buffer's
+            // live rows were just written: only its padding rows are cleared, by the kernel of the other path)
+            if ((rc = zero_pads(c, cur, C, Tc, B, s))) return rc;
+            size_t Tn = T;
+            for (size_t i = 0; i < c->lbuf.size(); ++i) {
+                const bool stage = i < c->down.size();
+                if (stage) Tn = (Tn + 2 * ((c->down[i].k - 1) / 2) - c->down[i].k) / 2 + 1;
+                const size_t ch = stage ? c->down[i].Co : c->inner;
+                GVC_CHECK_HIP(hipMemsetAsync(c->lbuf[i], 0, (size_t)B * (Tn + 2 * pad) * ch * sizeof(float), s));
+            }
+            c->cur_T = T; c->cur_B = B;
+        }
+        for (size_t i = 0; i < c->down.size(); ++i) {      // Conv1d(k, stride 2, pad (k-1)/2) + ReLU
+            const ConvW& w = c->down[i];
+            const int To = (Tc + 2 * ((w.k - 1) / 2) - w.k) / 2 + 1;
+            if ((rc = conv_lds(c, w, cur, Tc, 2, c->lbuf[i], To, B, ACT_RELU, nullptr, true, s))) return rc;
+            cur = c->lbuf[i]; C = w.Co; Tc = To;
+        }
+        float *t1 = c->lbuf[c->down.size()], *t2 = c->lbuf[c->down.size() + 1];
+        for (size_t r = 0; r + 2 < c->res.size(); r += 3) {   // ResBlock: conv3-ReLU-conv3-ReLU-conv1 + skip (over the block input)
+            if ((rc = conv_lds(c, c->res[r], cur, Tc, 1, t1, Tc, B, ACT_RELU, nullptr, true, s))) return rc;
+            if ((rc = conv_lds(c, c->res[r + 1], t1, Tc, 1, t2, Tc, B, ACT_RELU, nullptr, true, s))) return rc;
+            if ((rc = conv_lds(c, c->res[r + 2], t2, Tc, 1, cur, Tc, B, ACT_NONE, cur, true, s))) return rc;
+        }
+        float* enc = enc_out ? enc_out : c->enc;
+        if ((rc = conv_lds(c, c->last, cur, Tc, 1, enc, Tc, B, ACT_NONE, nullptr, false, s))) return rc;
+        const int dim = c->dm.codebook_dim;
+        hipLaunchKernelGGL(k_vq_argmin, dim3(B * Tc), dim3(kVqThreads), (dim + 4 * c->dm.num_tokens) * sizeof(float), s, enc, c->embed, c->ee, dim,
+                           c->dm.num_tokens, codes_out);
+        GVC_LAUNCH_CHECK();
+        return GVC_OK;
+    }
+    c->cur_T = -1;                        // (the input buffer now has this call's geometry: the other path clears its padding rows again)
     if ((rc = zero_pads(c, cur, C, Tc, B, s))) return rc;
     for (const ConvW& w : c->down) {                  // Conv1d(k, stride 2, pad (k-1)/2) + ReLU
         const int To = (Tc + 2 * ((w.k - 1) / 2) - w.k) / 2 + 1;

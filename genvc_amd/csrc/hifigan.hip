@@ -146,19 +146,6 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const float* x, long lon
     if (q == 0 && t0 + t < T) wav[(size_t)b * T + t0 + t] = tanhf(acc + bias[0]);
 }
 
-// conv_pre weights [Co][Ci][k] -> per channel slice s (CS channels) the FM16 copy of [Co][k*CS] (column tap*CS + c): [Ci/CS][FM16]
-__global__ void k_hf_pack_slices(const float* w, float* out, int Co, int Ci, int k, int CS) {
-    const int K = k * CS;
-    const size_t per = (size_t)Co * K, n4 = per * (Ci / CS) / 4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int sl = (int)(i * 4 / per);
-        const size_t r = i * 4 - (size_t)sl * per;
-        const int n = (int)(r / K), kc = (int)(r % K), tap = kc / CS, cl = kc % CS;
-        const float* src = w + ((size_t)n * Ci + sl * CS + cl) * k + tap;
-        *reinterpret_cast<float4*>(out + (size_t)sl * per + fm16_index(n, kc, K)) = make_float4(src[0], src[k], src[2 * k], src[3 * k]);
-    }
-}
-
 // p0 = scale * ((p0 + p1) + p2): the stage output for a consumer that cannot add the ResBlock planes itself (tiled GEMM)
 __global__ void k_sum_planes(float* p, long long ps, float scale, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -342,7 +329,7 @@ extern "C" int gvc_hifigan_bind_weight(gvc_hifigan* c, const char* name, const f
     if (n.rfind("conv_pre.", 0) == 0) {
         rc = hf_bind_conv(c->pre, is_bias, src, numel, name, s);
         if (!rc && is_w && c->pre_wp) {
-            hipLaunchKernelGGL(k_hf_pack_slices, dim3(512), dim3(256), 0, s, src, c->pre_wp, c->pre.Co, c->pre.Ci, c->pre.k, kPreSlice);
+            hipLaunchKernelGGL(k_conv_pack_slices, dim3(512), dim3(256), 0, s, src, c->pre_wp, c->pre.Co, c->pre.Ci, c->pre.k, kPreSlice);
             GVC_LAUNCH_CHECK();
         }
     }
@@ -421,9 +408,7 @@ static int hf_body(gvc_hifigan* c, int B, int T0, hipStream_t s, HfIn* out, int*
         A.T = T0; A.ntiles = pre_tiles; A.split = nsplit; A.wp_js = (long long)pre_tiles * pc.k * (kPreSlice / 16) * 64; A.cnt = c->cnt;
         A.job[0].wp = reinterpret_cast<const float4*>(c->pre_wp); A.job[0].b = pc.b; A.job[0].k = pc.k; A.job[0].dil = 1;
         A.job[0].row_off = -(pc.k - 1) / 2;
-        hipLaunchKernelGGL((k_conv_lds<kPreSlice, 8, 1, true>), dim3(cdiv(T0, 32), nsplit * pre_tiles, B), dim3(512),
-                           conv_lds_bytes(kPreSlice, pc.k, 1, true), s, A);
-        GVC_LAUNCH_CHECK();
+        if ((rc = launch_conv_lds_split(kPreSlice, A, B, conv_lds_bytes(kPreSlice, pc.k, 1, true), s))) return rc;
     } else if ((rc = hf_conv_gemm(c, pc, c->x0, c->x1, T0, B, 0.f, nullptr, nullptr, 0.f, s))) return rc;
     HfIn in;
     in.x = c->x1;
