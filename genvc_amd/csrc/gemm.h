@@ -28,6 +28,7 @@ struct GemmEpi {
     const float* resid;      // [M][ldr] or null (may alias C for in-place residual)
     int ldr;
     long long resid_batch_stride;
+    long long resid_batch_stride2; // two-level batches (GemmArgs.batch_inner): stride of the outer index
     const float* resid2;     // second residual with the layout of `resid` (HiFi-GAN resblock sum), or null
     float out_scale;         // 0 = none; otherwise the stored value is multiplied by it
     // GPT QKV scatter (prefill): n < d -> q[m][n]; else K/V cache rows
@@ -45,6 +46,9 @@ struct GemmArgs {
     const float* Wt; int ldw; long long w_batch_stride;
     int w_bf16;             // skinny kernels only: Wt is an FM16 copy of bf16 elements (unsigned short), widened in registers
     float* C; int ldc; long long c_batch_stride;
+    // two-level batches (ContentVec's grouped positional conv over a batch of utterances): batch index = outer * batch_inner + inner;
+    // A / C / resid move by (inner * stride + outer * stride2), weights and bias by the inner index only.  0: one level
+    int batch_inner; long long a_batch_stride2, c_batch_stride2;
     int M, N, K;
     // implicit im2col for dilated convolutions over a time-major buffer: when conv_cin > 0, column k of A is
     // (tap = k / conv_cin, ci = k % conv_cin) and lives at A[m*lda + tap*conv_tap_stride + ci]
@@ -58,6 +62,11 @@ struct GemmArgs {
     float* work;             // [batch][SK][M][N]
     GemmEpi e;
 };
+
+__device__ __forceinline__ long long gemm_boff(const GemmArgs& G, int batch, long long s1, long long s2) {
+    return G.batch_inner > 0 ? (long long)(batch % G.batch_inner) * s1 + (long long)(batch / G.batch_inner) * s2 : (long long)batch * s1;
+}
+__device__ __forceinline__ int gemm_binner(const GemmArgs& G, int batch) { return G.batch_inner > 0 ? batch % G.batch_inner : batch; }
 
 // everything after the bias (callers whose lanes keep one column add the bias value they loaded once)
 __device__ __forceinline__ void gemm_store_nb(const GemmArgs& G, int batch, int m, int n, float v) {
@@ -82,15 +91,15 @@ __device__ __forceinline__ void gemm_store_nb(const GemmArgs& G, int batch, int 
         }
         return;
     }
-    if (e.resid) v += e.resid[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
-    if (e.resid2) v += e.resid2[batch * e.resid_batch_stride + (size_t)m * e.ldr + n];
+    if (e.resid) v += e.resid[gemm_boff(G, batch, e.resid_batch_stride, e.resid_batch_stride2) + (size_t)m * e.ldr + n];
+    if (e.resid2) v += e.resid2[gemm_boff(G, batch, e.resid_batch_stride, e.resid_batch_stride2) + (size_t)m * e.ldr + n];
     if (e.out_scale != 0.f) v *= e.out_scale;
     if (e.c_fm16) { G.C[fm16_index(m, n, G.N)] = v; return; }
-    G.C[batch * G.c_batch_stride + (size_t)m * G.ldc + n] = v;
+    G.C[gemm_boff(G, batch, G.c_batch_stride, G.c_batch_stride2) + (size_t)m * G.ldc + n] = v;
 }
 
 __device__ __forceinline__ void gemm_store(const GemmArgs& G, int batch, int m, int n, float v) {
-    if (G.e.bias) v += G.e.bias[batch * G.e.bias_batch_stride + n];
+    if (G.e.bias) v += G.e.bias[gemm_binner(G, batch) * G.e.bias_batch_stride + n];
     gemm_store_nb(G, batch, m, n, v);
 }
 

@@ -18,8 +18,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmArgs G) {
     const int kbeg = sk * tps * BK;
     const int kend = min(G.K, kbeg + tps * BK);
     const int nt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-    const float* Ab = G.A + batch * G.a_batch_stride;
-    const float* Wb = G.Wt + batch * G.w_batch_stride;
+    const float* Ab = G.A + gemm_boff(G, batch, G.a_batch_stride, G.a_batch_stride2);
+    const float* Wb = G.Wt + gemm_binner(G, batch) * G.w_batch_stride;
 
     float4 ra[2], rb[2];
     auto load_tile = [&](int kt) {

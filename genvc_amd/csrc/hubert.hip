@@ -618,19 +618,20 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     // conv padding rows, and the rows of padding frames, are zero from here on
     hipLaunchKernelGGL(k_hb_zero_pad, dim3(64, B), dim3(256), 0, s, c->xp, E, F, c->pad_front, c->pad_back, c->fmask);
     GVC_LAUNCH_CHECK();
-    // tmp = x + gelu(pos_conv(x) + bias): one batched GEMM per batch element, batch = group
-    for (int b = 0; b < B; ++b) {
+    // tmp = x + gelu(pos_conv(x) + bias): ONE batched GEMM, batch = (utterance, group)
+    {
         GemmArgs G;
         memset(&G, 0, sizeof(G));
         const int cg = c->cg;
-        G.A = c->xp + b * xp_bs; G.lda = E; G.a_batch_stride = cg;
+        G.batch_inner = D.pos_conv_groups;
+        G.A = c->xp; G.lda = E; G.a_batch_stride = cg; G.a_batch_stride2 = xp_bs;
         G.conv_cin = cg; G.conv_tap_stride = E;
         G.Wt = c->pos.w; G.ldw = kp * cg; G.w_batch_stride = (long long)cg * kp * cg;
-        G.C = c->tmp + (size_t)b * F * E; G.ldc = E; G.c_batch_stride = cg;
+        G.C = c->tmp; G.ldc = E; G.c_batch_stride = cg; G.c_batch_stride2 = (long long)F * E;
         G.M = F; G.N = cg; G.K = kp * cg; G.work = c->work;
         G.e.bias = c->pos.b; G.e.bias_batch_stride = cg; G.e.act = ACT_GELU_ERF;
-        G.e.resid = c->xp + b * xp_bs + (size_t)c->pad_front * E; G.e.ldr = E; G.e.resid_batch_stride = cg;
-        if ((rc = launch_gemm_cap(G, D.pos_conv_groups, c->work_cap, s))) return rc;
+        G.e.resid = c->xp + (size_t)c->pad_front * E; G.e.ldr = E; G.e.resid_batch_stride = cg; G.e.resid_batch_stride2 = xp_bs;
+        if ((rc = launch_gemm_cap(G, B * D.pos_conv_groups, c->work_cap, s))) return rc;
     }
     const bool skinny = c->skinny && (rows <= 128 || (c->strip && E % 64 == 0 && D.ffn_dim % 64 == 0));
     const bool strip = rows > 128;
