@@ -210,7 +210,7 @@ def offline_leg(wl, rank, world, dist, device):
     srcs = [synth.synth_audio(500 + i, "src", int(SRC_SECONDS * 16000)) for i in range(OFFLINE_UTTS)]
     ref = synth.synth_audio(7, "ref", int(REF_SECONDS * 24000))
     # fixed token budgets by segment duration (23.4375 tokens per second: 141 for the 6 s class, 94 for the 4 s class)
-    kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141, tokens_per_second=23.4375)
+    kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141, tokens_per_second=23.4375, group=int(os.environ.get("GVC_BENCH_OFFLINE_GROUP", "48")))     # decode steps between two host looks at the finished flags (library default 16: +0.5 %)
 
     def run(mb, r, w):
         convert_offline(m, srcs[:mb * w], ref, micro_batch=mb, rank=r, world=w, **kw)        # graph capture / warm-up, one wave

@@ -211,6 +211,7 @@ class GPT(nn.Module):
         Returns a list of int64 [B_i, n_i] (reference gpt.py:594-609 per group)."""
         self._need_engine()
         kw = dict(generate_kwargs)
+        group = kw.pop("group", 16)          # decode steps per engine call (one host look at the finished flags per call)
         budgets = kw.get("max_new_tokens")
         if isinstance(budgets, (list, tuple)):
             if len(budgets) != len(groups):
@@ -239,7 +240,6 @@ class GPT(nn.Module):
             return outs
         if stats is not None:
             stats["joint"] += 1
-        group = kw.pop("group", 16)
         dev = groups[0][1].device
         max_new = kw.get("max_new_tokens") or self.max_gen_mel_tokens
         # rows in order of falling budget: the live streams are always the first rows of every buffer
