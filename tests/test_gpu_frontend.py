@@ -124,6 +124,36 @@ def test_hifigan_fallback_paths_match_reference(gold, monkeypatch, mode):
         eng.close()
 
 
+@pytest.mark.parametrize("cfg", [
+    # other widths / rates / taps / dilations than the trained generator: every k_conv_lds instance, frame counts that are not whole
+    # tiles, ResBlock counts that keep the launch-per-conv path, a stage narrower than the LDS kernel takes
+    dict(input_feat_dim=512, upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3], [3, 5], [1, 7]],
+         upsample_rates=[4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4]),
+    dict(input_feat_dim=256, upsample_initial_channel=128, resblock_kernel_sizes=[5, 3, 9], resblock_dilation_sizes=[[2, 1], [1, 4], [3, 2]],
+         upsample_rates=[8, 2], upsample_kernel_sizes=[16, 4]),
+    dict(input_feat_dim=1024, upsample_initial_channel=256, resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [2, 6]],
+         upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8]),
+    dict(input_feat_dim=128, upsample_initial_channel=64, resblock_kernel_sizes=[3, 5, 7], resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]],
+         upsample_rates=[4, 4, 4], upsample_kernel_sizes=[8, 8, 8]),
+], ids=["4stages_k11", "2stages", "2resblocks", "narrow"])
+def test_hifigan_other_configurations_match_oracle(cfg):
+    """row f1 beyond the trained configuration: generators of other shapes against the oracle's HiFi-GAN (oracle/genvc_oracle.py
+    hifigan_forward, itself pinned to the reference class by tests/test_oracle.py)"""
+    from genvc_amd.engine import HifiganEngine
+    from oracle import genvc_oracle as O
+    c = dict(gcfg.DEFAULT_VOCODER, **cfg)
+    w = synth.make_weights(21, synth.hifigan_weight_spec(c))
+    eng = HifiganEngine(c, max_batch=2, max_frames=64)
+    eng.bind({k: v.to(DEV) for k, v in w.items()})
+    for B, n in ((1, 5), (2, 9), (1, 16), (2, 1)):
+        lat = synth.uniform(21, f"lat_{B}_{n}", (B, n, c["input_feat_dim"]), 1.0)
+        exp = O.vocode_latents(w, c, lat)
+        got = eng.forward_latents(lat.to(DEV), 4).cpu()
+        assert got.shape == exp.shape
+        np.testing.assert_allclose(got.numpy(), exp.numpy(), atol=1e-4)
+    eng.close()
+
+
 def test_hifigan_whole_call_graph_follows_the_callers_buffers(gold):
     """the whole call is one graph whose first and last kernel nodes carry the caller's pointers: different input / output
     tensors on every call (and both entry points) must be honoured"""
