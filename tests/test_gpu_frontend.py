@@ -74,6 +74,37 @@ def test_dvae_codes_match_reference(gold):
     assert n_exempt_diff <= max(2, (n_all - n_safe) // 4)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(num_channels=256, hidden_dim=256, codebook_dim=256, num_resnet_blocks=2, kernel_size=3, num_layers=2),     # 1 / 1 / 2 channel slices
+    dict(num_channels=512, hidden_dim=256, codebook_dim=128, num_resnet_blocks=1, kernel_size=5, num_layers=3),     # 5 taps, 3 stages, 4 slices
+    dict(num_channels=256, hidden_dim=128, codebook_dim=64, num_resnet_blocks=2, kernel_size=3, num_layers=2),      # 128-channel stage: tiled GEMM only
+], ids=["2slices", "5taps_3stages", "gemm_only"])
+def test_dvae_other_configurations_match_oracle(cfg):
+    """row a5 beyond the trained configuration: encoders of other shapes against the oracle (oracle/genvc_oracle.py dvae_encode, pinned to
+    the reference class by tests/test_oracle.py); frame counts either side of the switch between the one-round-trip conv kernel
+    (B x T <= 600) and the tiled GEMM, in an order that changes the buffer geometry between calls"""
+    from genvc_amd.engine import DvaeEngine
+    from oracle import genvc_oracle as O
+    c = dict(gcfg.DEFAULT_CONTENT_DVAE, **cfg)
+    w = synth.make_weights(31, synth.dvae_weight_spec(c))
+    eng = DvaeEngine(c, max_batch=3, max_frames=400)
+    eng.bind({k: v.to(DEV) for k, v in w.items()})
+    for B, T in ((1, 49), (3, 350), (2, 17), (1, 333), (3, 49), (1, 49)):
+        feat = synth.uniform(31, f"feat_{B}_{T}", (B, c["num_channels"], T), 1.0)
+        ref = O.dvae_encode(w, feat)
+        codes, enc = eng.encode(feat.to(DEV), return_enc=True)
+        assert enc.shape == ref.shape
+        np.testing.assert_allclose(enc.cpu().numpy(), ref.numpy(), atol=3e-5)
+        # codes: equal wherever the oracle's own decision is not a near-tie
+        flat = ref.reshape(-1, ref.shape[-1])
+        dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ w["codebook.embed"] + w["codebook.embed"].pow(2).sum(0, keepdim=True)
+        top2 = (-dist).topk(2, dim=1).values
+        safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).view(ref.shape[:-1]).numpy()
+        exp = O.vq_indices(ref, w["codebook.embed"]).numpy()
+        assert safe.mean() > 0.9 and np.array_equal(codes.cpu().numpy()[safe], exp[safe])
+    eng.close()
+
+
 def test_vq_first_index_wins_ties():
     from genvc_amd.engine import vq_argmin
     embed = synth.uniform(3, "e", (64, 32), 1.0).to(DEV)
