@@ -250,6 +250,25 @@ def test_hubert_matches_hf_golden_and_oracle(gold):
         eng.close()
 
 
+def test_hubert_other_configuration_matches_oracle():
+    """row f3 beyond HuBERT-base: 256-channel feature extractor (another instance of the one-round-trip conv kernel for the short
+    layers), 256-wide encoder with 4 heads, batches of 1-3 at lengths either side of the conv kernel's frame limit"""
+    from genvc_amd.engine import HubertEngine
+    from oracle import genvc_oracle as O
+    c = dict(conv_layers=[(256, 10, 5)] + [(256, 3, 2)] * 4 + [(256, 2, 2)] * 2, embed_dim=256, layers=3, heads=4, ffn_dim=512,
+             pos_conv_kernel=128, pos_conv_groups=16, final_dim=256)
+    w = synth.make_weights(41, synth.hubert_weight_spec(c))
+    eng = HubertEngine(c, max_batch=3, max_samples=16000 * 5)
+    eng.bind({k: v.to(DEV) for k, v in w.items()})
+    for B, T in ((1, 16000), (3, 16000), (2, 70000), (1, 8000)):
+        wav = torch.cat([synth.synth_audio(41 + b, f"wav{T}", T) for b in range(B)], 0)
+        ref = O.hubert_extract_features(w, c, wav)
+        got = eng.forward(wav.to(DEV)).cpu()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=5e-4)
+    eng.close()
+
+
 def test_hubert_rejects_short_and_oversized_input():
     from genvc_amd.engine import HubertEngine
     from genvc_amd._lib import GenvcHipError
