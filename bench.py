@@ -1,6 +1,10 @@
 """Headline benchmark of the GenVC codec-token generation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` -- one rank per GPU over RCCL; it
+refuses to start when fewer than N GPUs are visible.  Launched BY torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 Workload (BASELINE.json configs[1]): GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU.
 A "step" = one synthetic utterance (10 s source @16 kHz, 3 s reference @24 kHz) pushed through the hot
@@ -24,6 +28,12 @@ Extra legs, outside the K timed steps (their numbers are extra keys of the same 
     scales with GPUs).  `--no-offline` skips it.
   * `harness` (rank 0): the same utterance through inference_utils.synthesize_utt_streaming with the inputs in HOST memory --
     the reference's latency window (clock before the host->device copy, inference_utils.py:148) next to the device-only one.
+
+  * `streams8_bf16_kv` (N = 1): BASELINE configs[3] -- 8 concurrent streams stepped together, bf16 weights + bf16 KV cache.
+  * `prefill_5x110` (N = 1): the batched prefill of BASELINE configs[4] (5 segments x 110 rows) with its own roofline entry
+    (`bound: mfma`, achieved TFLOP/s against the 157.3 TFLOP/s fp32-MFMA peak; FLOPs per SURVEY.md 8d).
+  * `config4` (every N): BASELINE configs[4] -- 30 s source + 10 s reference, top_k=50: mel + Perceiver on 563 + 376 frames, the five
+    6 s segments as ONE batch (ContentVec, DVAE, 5 x 110-row prefill, 5-stream sampled decode of 141 steps, latent re-pass, vocoder).
 
 `--streams B` (default 1 = the headline configuration) steps B concurrent streams per GPU together (BASELINE
 configs[3] shape: shared launches, one decode step for all streams; the MFMA rows path from 5 streams up); a step is
@@ -51,6 +61,7 @@ KERNEL_NAMES = ["c_attn_gemv(ln1+qkv)", "attention+attn_c_proj(fused,head-split)
                 "mlp_c_fc_gemv(resid-sum+ln2+gelu)", "mlp_c_proj_gemv(resid)", "head_gemv(2xln+mel_head)"]
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 OFFLINE_UTTS, OFFLINE_MICRO_BATCH = 64, 8     # BASELINE configs[2]; fixed per-GPU micro-batch
+MFMA_F32_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md: dense fp32 matrix (v_mfma_f32_32x32x2_f32) peak
 OFFLINE_SEGMENTS = 2                          # a 10 s utterance at seg_len 6 s = a 6 s and a 4 s segment
 
 
@@ -273,6 +284,227 @@ def harness_leg(wl, reps=3):
                       "(the reference reads its clock without a sync, inference_utils.py:148,208-211)", "runs": reps}
 
 
+def prefill_flops(dims, B, T):
+    """prefill of T rows per stream = 2 T L 12 d^2 (the four projections) + 4 L d T (T + 1) / 2 (causal attention)"""
+    d, L = dims["d_model"], dims["n_layer"]
+    return B * (2 * T * L * 12 * d * d + 4 * L * d * T * (T + 1) / 2)
+
+
+def _timed(fn, reps, warm=2):
+    """mean ms of fn() over `reps` back-to-back calls (events on the launch stream)"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def prefill_leg(wl, B=5, Tc=75, reps=6):
+    """BASELINE configs[4]'s GPT prefill: B segments x (32 + Tc + 2 + 1) rows in one batched call (reference
+    layers/gpt_inference.py:81-91), fp32 MFMA.  roofline: achieved = SURVEY 8d FLOPs / mean call time."""
+    dev, eng, dims = wl.dev, wl.eng, wl.dims
+    cond = synth.uniform(1, "c", (B, 32, dims["d_model"]), 1.0).to(dev)
+    codes = synth.integers(1, "k", (B, Tc), 256).to(dev).int()
+    slots = torch.arange(B, device=dev, dtype=torch.int32)
+    prefix = eng.prefix_embeddings(cond, codes)
+    T = prefix.shape[1] + 1
+    ms = _timed(lambda: eng.prefill(slots, prefix, want_outputs=False), reps)
+    fl = prefill_flops(dims, B, T)
+    tf = fl / (ms * 1e-3) / 1e12
+    out = {"workload": f"batched GPT prefill, {B} segments x {T} rows (6 s segments: 32 conditioning + {Tc} + 2 text rows + start), fp32 "
+                       "(BASELINE configs[4] prefill shape; GenVC_large := GenVC_small dims, no checkpoint ships)",
+           "ms": ms, "gflop": fl / 1e9,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": None, "flops_per_call": fl,
+                        "kernel": "k_gemm_strip (c_attn / attn c_proj / c_fc / mlp c_proj) + k_attention_tile + k_ln_sum_rows, 30 layers"}}
+    # the single-stream shapes of the streaming path beside it (48 rows: first 1 s chunk; 110 rows: a 6 s segment)
+    for b1, tc1 in ((1, 13), (1, 75)):
+        c1, k1 = cond[:b1].contiguous(), synth.integers(2, "k", (b1, tc1), 256).to(dev).int()
+        p1 = eng.prefix_embeddings(c1, k1)
+        s1 = slots[:b1].contiguous()
+        m1 = _timed(lambda: eng.prefill(s1, p1, want_outputs=False), reps)
+        t1 = p1.shape[1] + 1
+        out[f"prefill_1x{t1}_ms"] = m1
+        out[f"prefill_1x{t1}_mfma_frac"] = prefill_flops(dims, b1, t1) / (m1 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS
+    # the 16 uncached rows of a later 1 s chunk (conditioning rows cached): the one-launch rows step
+    c1, k1 = cond[:1].contiguous(), synth.integers(2, "k", (1, 13), 256).to(dev).int()
+    p1, s1 = eng.prefix_embeddings(c1, k1), slots[:1].contiguous()
+    eng.prefill(s1, p1, want_outputs=False)
+    out["prefill_cached_16_rows_ms"] = _timed(lambda: eng.prefill(s1, p1, want_outputs=False, n_cached=32), reps)
+    return out
+
+
+def streams_leg(device, rank, streams=8, weights="bf16_kv", steps=3):
+    """BASELINE configs[3]: `streams` concurrent streams on one GPU, bf16 weights + bf16 KV cache (fp32 accumulation), every stream
+    converted as synthesize_utt_streaming converts it alone; the streams share the launches (one decode step for all)."""
+    wl = Workload(device, rank, streams, weights, max_slots=max(8, streams))
+    wl.utterance(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for u in range(steps):
+        wl.utterance(u + 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    wl.utterance(0, record=True)
+    torch.cuda.synchronize()
+    first_ms = wl.ev[0].elapsed_time(wl.ev[1])
+    # decode-step time of the batch: graph-replayed generation steps at the chunk's contexts
+    n = STEPS_PER_CHUNK
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    cond = wl.model.get_gpt_cond_latents(wl.ref[0], 24000).expand(streams, -1, -1).contiguous()
+    wl.eng.prefill(wl.slots, wl.eng.prefix_embeddings(cond, torch.zeros(streams, wl.Tc, device=device, dtype=torch.int32)), want_outputs=False)
+    wl.ids.fill_(1)
+    wl.ids[:, wl.P] = wl.dims["start_audio_token"]
+    wl.ids_len.fill_(wl.P + 1)
+    wl.fin.zero_()
+    tv, lv = wl.toks[:, :n], wl.lats[:, :n]
+    wl.eng.generate(wl.slots, wl.ids, wl.ids_len, wl.fin, wl.sp, 0, GROUP, tv, lv, max_keys=wl.P + 1 + n)
+    ev[0].record()
+    wl.eng.generate(wl.slots, wl.ids, wl.ids_len, wl.fin, wl.sp, GROUP, n - GROUP, tv, lv, max_keys=wl.P + 1 + n)
+    ev[1].record()
+    torch.cuda.synchronize()
+    step_us = ev[0].elapsed_time(ev[1]) / (n - GROUP) * 1e3
+    variant = wl.eng.decode_variant()
+    wb, kvb = (4, 4) if weights == "fp32" else (2, 2 if weights == "bf16_kv" else 4)
+    s_mid = wl.P + 1 + n // 2
+    by = step_bytes(wl.dims, s_mid, wb, kvb) + (streams - 1) * (2 * wl.dims["n_layer"] * (s_mid + 1) * wl.dims["d_model"]) * kvb
+    out = {"workload": f"GenVC_large (:= GenVC_small dims) streaming, 1 s chunks, top_k=1, {streams} concurrent streams on one GPU stepped "
+                       f"together, weights/KV {weights}, fp32 accumulation (BASELINE configs[3])",
+           "utts_per_s": streams / dt, "rtf_per_stream": dt / SRC_SECONDS, "first_chunk_latency_ms": first_ms,
+           "decode_step_us": step_us, "decode_variant": variant,
+           "roofline": {"bound": "hbm", "achieved": by / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": by,
+                        "kernel": "k_rows_persist<8> (one decode step of 8 streams, sampler + head launches included in the time)"}}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+C4_SRC_SECONDS, C4_REF_SECONDS, C4_SEG_SECONDS, C4_TOP_K = 30.0, 10.0, 6.0, 50
+
+
+class Config4:
+    """BASELINE configs[4]: 30 s source + 10 s reference, top_k=50.  The conversion is inference_utils.synthesize_utt's (mel +
+    Perceiver per 6 s reference chunk and the mean; per 6 s source segment ContentVec -> DVAE -> generate -> latent re-pass; one
+    vocoder call over all latents) with the five segments -- independent given the conditioning latents,
+    /root/reference/inference/inference_utils.py:43-77 -- carried as ONE batch: 5 x 110-row prefill, 5 streams per decode step.
+    Fixed token budget (141 per segment); sampling never finishes a row (eos = -1)."""
+
+    def __init__(self, wl, rank):
+        self.wl, m = wl, wl.model
+        dev = wl.dev
+        self.ref = synth.synth_audio(900 + rank, "ref", int(C4_REF_SECONDS * 24000)).to(dev)
+        n_seg = int(C4_SRC_SECONDS / C4_SEG_SECONDS)
+        self.src = synth.synth_audio(901 + rank, "src", int(C4_SRC_SECONDS * 16000)).view(n_seg, -1).contiguous().to(dev)
+        self.B = n_seg
+        self.n_new = int(round(C4_SEG_SECONDS * 23.4375)) + 0            # 141
+        from genvc_amd.engine import sample_params
+        self.sp = sample_params(dict(gcfg.DEFAULT_SAMPLING, top_k=C4_TOP_K), wl.dims["num_audio_tokens"], -1, 17)
+        self.slots = torch.arange(self.B, device=dev, dtype=torch.int32)
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        self.dev = dev
+
+    def utterance(self, record=False):
+        wl, m, eng, B, n = self.wl, self.wl.model, self.wl.eng, self.B, self.n_new
+        ev = self.ev
+        if record:
+            ev[0].record()
+        cond = m.get_gpt_cond_latents(self.ref, 24000)                    # 6 s + 4 s chunks: mel + Perceiver on 563 + 376 frames, mean
+        if record:
+            ev[1].record()
+        feat = m.content_extractor.extract_content_features(self.src)     # [5, 299, 256]
+        codes = m.content_dvae._engine.encode(feat, frames_major=True)    # [5, 75]
+        if record:
+            ev[2].record()
+        condB = cond.expand(B, -1, -1).contiguous()
+        prefix = eng.prefix_embeddings(condB, codes)
+        P = prefix.shape[1]
+        ids = torch.ones(B, P + 1 + n + 8, device=self.dev, dtype=torch.int32)
+        ids[:, P] = wl.dims["start_audio_token"]
+        ids_len = torch.full((B,), P + 1, device=self.dev, dtype=torch.int32)
+        fin = torch.zeros(B, device=self.dev, dtype=torch.int32)
+        toks = torch.zeros(B, n, device=self.dev, dtype=torch.int32)
+        lats = torch.empty(B, n, wl.dims["d_model"], device=self.dev)
+        eng.prefill(self.slots, prefix, want_outputs=False)               # 5 x 110 rows
+        if record:
+            ev[3].record()
+        for g in range(0, n, 48):
+            k = min(48, n - g)
+            eng.generate(self.slots, ids, ids_len, fin, self.sp, g, k, toks, lats, max_keys=P + 1 + g + k)
+        if record:
+            ev[4].record()
+        lat = eng.latents(self.slots, prefix, toks)                       # latent re-pass (gpt.py:375-508), 5 x (110 + 141 + 4) rows
+        if record:
+            ev[5].record()
+        self.wav = m.hifigan.forward_latents(lat.reshape(1, B * n, -1), 4)    # one vocoder call over all latents (inference_utils.py:79-87)
+        if record:
+            ev[6].record()
+        self.P = P
+        return toks
+
+
+def config4_leg(wl, rank, world, dist, device, steps=3):
+    c4 = Config4(wl, rank)
+    c4.utterance()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        toks = c4.utterance()
+    if dist is not None:                                    # the batched offline path's collective: token ids of every rank's utterance
+        parts = [torch.empty_like(toks) for _ in range(world)]
+        dist.all_gather(parts, toks)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    c4.utterance(record=True)
+    torch.cuda.synchronize()
+    st = [c4.ev[i].elapsed_time(c4.ev[i + 1]) for i in range(6)]
+    T = c4.P + 1
+    fl_prefill = prefill_flops(wl.dims, c4.B, T)
+    d = wl.dims["d_model"]
+    # Perceiver MACs per SURVEY 8d, F frames: 4 layers x [(32+F) d 1024 + 32 d 512 + 2*8*32 (32+F) 64 + 32 512 d + 32 d 5460 + 32 2730 d] + F 80 d
+    def perc(F):
+        return 2.0 * (4 * ((32 + F) * d * 1024 + 32 * d * 512 + 2 * 8 * 32 * (32 + F) * 64 + 32 * 512 * d + 32 * d * 5460 + 32 * 2730 * d) + F * 80 * d)
+    fl_perc = perc(563) + perc(376)
+    return {"workload": f"GenVC_large (:= GenVC_small dims) non-streaming, {C4_SRC_SECONDS:.0f} s source + {C4_REF_SECONDS:.0f} s reference, "
+                        f"top_k={C4_TOP_K} (BASELINE configs[4]): Perceiver on 563 + 376 mel frames; five 6 s segments as one batch "
+                        f"(5 x {T}-row prefill, 5-stream sampled decode x {c4.n_new} steps, latent re-pass, one vocoder call); one utterance per GPU at a time",
+            "n_gpus": world, "utts_per_s": steps * world / dt, "rtf": dt / steps / C4_SRC_SECONDS, "ms_per_utterance": dt / steps * 1e3,
+            "stages_ms": {"mel+perceiver(563+376 frames)": st[0], "contentvec+dvae(5 x 6 s)": st[1], f"prefix+prefill(5x{T})": st[2],
+                          f"decode({c4.n_new} steps x 5 streams, top_k={C4_TOP_K})": st[3], "latent re-pass": st[4], "vocoder": st[5]},
+            "prefill_mfma_frac": fl_prefill / (st[2] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "perceiver_mfma_frac_incl_mel": fl_perc / (st[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "decode_step_us": st[3] / c4.n_new * 1e3, "decode_variant": wl.eng.decode_variant()}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `torch.distributed.run` with one rank per GPU"""
+    import socket
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not os.environ.get("GVC_BENCH_SAME_DEVICE"):
+        sys.exit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this node (set GVC_BENCH_SAME_DEVICE=1 with "
+                 "GVC_BENCH_BACKEND=gloo for a dry run of the multi-rank path on one GPU)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,15 +513,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-offline", action="store_true", help="skip the batched-offline leg (BASELINE configs[2])")
     ap.add_argument("--no-harness", action="store_true", help="skip the harness-level leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] / prefill legs")
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
     ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv"],
                     help="GPT weight / KV-cache storage (fp32 = headline configuration; bf16_kv with --streams 8 = BASELINE configs[3])")
     args = ap.parse_args()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                         # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: the JSON line must describe the job that ran"
     from genvc_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):       # a checkout without the in-tree build: compile it here (hipcc, gfx950)
         if rank == 0:
@@ -345,6 +580,14 @@ def main():
         dt = float(t.item())
 
     offline = offline_leg(wl, rank, world, dist, device) if do_offline else None
+    do_extra = headline and args.weights == "fp32" and not args.no_extra
+    config4 = config4_leg(wl, rank, world, dist, device) if do_extra else None
+    rccl_ranks = None
+    if dist is not None:
+        # ranks that really took part in a collective on the job's backend (nccl = RCCL): every rank contributes a one
+        ones = [torch.zeros(1, device=device, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(ones, torch.ones(1, device=device, dtype=torch.int32))
+        rccl_ranks = int(torch.cat(ones).sum().item())
 
     if rank == 0:
         # latency / per-stage numbers from one recorded utterance (device events on the launch stream)
@@ -411,7 +654,9 @@ def main():
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "utterances/s (streaming, 1 s chunks; with RTF and first-chunk latency)",
-            "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world,
+            "collective_backend": None if dist is None else dist.get_backend(), "rccl_ranks": rccl_ranks,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.weights == "fp32" else "bf16 storage, f32 arithmetic", "data": "synthetic", "weights": args.weights,
             "rtf": (dt / args.steps) / SRC_SECONDS, "first_chunk_latency_ms": first_ms, "streams_per_gpu": args.streams,
@@ -436,10 +681,16 @@ def main():
         if offline is not None:
             out["offline"] = offline
             out["offline_utts_per_s"] = offline["offline_utts_per_s"]
+        if config4 is not None:
+            out["config4"] = config4
+        if do_extra and world == 1:
+            out["prefill_5x110"] = prefill_leg(wl)
         if headline and not args.no_harness:
             out["harness"] = harness_leg(wl)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
+        if do_extra and world == 1:
+            out["streams8_bf16_kv"] = streams_leg(device, rank)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -275,6 +275,7 @@ struct gvc_gpt {
     float* r_wpack = nullptr;         // packed weights [layer][256][192 KiB]
     float* r_bufs = nullptr;          // hand-off buffers, two parities
     unsigned long long* r_dbg = nullptr;   // GVC_PERSIST_STAMPS
+    std::vector<char> r_dirty;         // per layer: a matrix was re-bound after the pack was built (gvc_gpt_bind_weight) -> repack before use
     size_t r_lds = 0;
     int rows_keys_hint = 0;           // cached positions the longest stream of the running call reaches (set by the entry points)
     int r_split1 = 0, r_split2 = 0;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
@@ -437,6 +438,7 @@ static int transpose_w(float* dst, const float* src, int64_t numel, int K, int N
     return GVC_OK;
 }
 
+static void mark_rows_pack_dirty(gvc_gpt* c, int li);
 extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* src, int64_t numel, gvc_stream sv) {
     GVC_REQUIRE(c && name && src, GVC_ERR_ARG, "gvc_gpt_bind_weight: null argument");
     hipStream_t s = (hipStream_t)sv;
@@ -469,15 +471,15 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
         GptLayer& ly = c->layers[li];
         if (rest == "ln_1.weight") rc = copy_w(ly.ln1_w, src, numel, d, name, s);
         else if (rest == "ln_1.bias") rc = copy_w(ly.ln1_b, src, numel, d, name, s);
-        else if (rest == "attn.c_attn.weight") rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f, ly.qkv_h);
+        else if (rest == "attn.c_attn.weight") { rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f, ly.qkv_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "attn.c_attn.bias") rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s);
-        else if (rest == "attn.c_proj.weight") rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f, ly.proj_h);
+        else if (rest == "attn.c_proj.weight") { rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f, ly.proj_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "attn.c_proj.bias") rc = copy_w(ly.proj_b, src, numel, d, name, s);
         else if (rest == "ln_2.weight") rc = copy_w(ly.ln2_w, src, numel, d, name, s);
         else if (rest == "ln_2.bias") rc = copy_w(ly.ln2_b, src, numel, d, name, s);
-        else if (rest == "mlp.c_fc.weight") rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f, ly.fc_h);
+        else if (rest == "mlp.c_fc.weight") { rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f, ly.fc_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "mlp.c_fc.bias") rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s);
-        else if (rest == "mlp.c_proj.weight") rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f, ly.p2_h);
+        else if (rest == "mlp.c_proj.weight") { rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f, ly.p2_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "mlp.c_proj.bias") rc = copy_w(ly.p2_b, src, numel, d, name, s);
         else known = false;   // attn.bias / attn.masked_bias buffers of 4.33-era checkpoints
     } else {
@@ -485,6 +487,11 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
     }
     if (rc == GVC_OK && known) c->bound[n] = 1;
     return rc;
+}
+
+// a block matrix of layer li was (re)bound: the one-launch rows step's packed copy of that layer must be rebuilt before its next use
+static void mark_rows_pack_dirty(gvc_gpt* c, int li) {
+    if (c->r_ready == 1 && li < (int)c->r_dirty.size()) c->r_dirty[li] = 1;
 }
 
 extern "C" int gvc_gpt_missing_weights(gvc_gpt* c) {
@@ -781,7 +788,31 @@ static void rows_persist_release(gvc_gpt* c) {
 
 // packed weight copy, per-layer table, hand-off buffers; called outside stream capture (synchronous).  Anything the device
 // refuses (memory, LDS opt-in, residency) switches the path off for this context instead of failing the call.
+static void rows_pack_layer(gvc_gpt* c, int l) {
+    const GptLayer& ly = c->layers[l];
+    const int wsh = c->bf16 ? 1 : 0;
+    float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * (kRWgLayerBytes >> wsh));
+    if (wsh) hipLaunchKernelGGL(k_pack_rows_weights<1>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
+                                (const float*)ly.fc_w, (const float*)ly.p2_w);
+    else hipLaunchKernelGGL(k_pack_rows_weights<0>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
+                            (const float*)ly.fc_w, (const float*)ly.p2_w);
+}
+
 static int rows_persist_prepare(gvc_gpt* c) {
+    if (c->r_ready == 1 && !c->r_dirty.empty()) {
+        // weights re-bound since the pack was built (a second GptEngine.bind on the same context): the packed copy of those layers is
+        // stale.  Rare and outside capture: wait for the bind stream's transposes, repack, wait again.
+        bool any = false;
+        for (char f : c->r_dirty) any = any || f;
+        if (any) {
+            GVC_CHECK_HIP(hipDeviceSynchronize());
+            for (int l = 0; l < c->dm.n_layer; ++l)
+                if (c->r_dirty[l]) rows_pack_layer(c, l);
+            GVC_CHECK_HIP(hipGetLastError());
+            GVC_CHECK_HIP(hipDeviceSynchronize());
+            std::fill(c->r_dirty.begin(), c->r_dirty.end(), 0);
+        }
+    }
     if (c->r_ready != 0) return GVC_OK;
     const int L = c->dm.n_layer;
     c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + 3 * kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
@@ -808,21 +839,22 @@ static int rows_persist_prepare(gvc_gpt* c) {
         RowsLayer& p = t[l];
         p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_b = ly.qkv_b; p.proj_b = ly.proj_b; p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b;
         p.fc_b = ly.fc_b; p.p2_b = ly.p2_b; p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
-        float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * (kRWgLayerBytes >> wsh));
-        if (wsh) hipLaunchKernelGGL(k_pack_rows_weights<1>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
-                                    (const float*)ly.fc_w, (const float*)ly.p2_w);
-        else hipLaunchKernelGGL(k_pack_rows_weights<0>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
-                                (const float*)ly.fc_w, (const float*)ly.p2_w);
+        rows_pack_layer(c, l);
     }
     if (hipGetLastError() != hipSuccess || hipMemcpy(c->r_layers, t.data(), L * sizeof(RowsLayer), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->r_bufs, 0xff, rows_buf_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         rows_persist_release(c);
         return GVC_OK;
     }
-    if (getenv("GVC_PERSIST_STAMPS")) {
-        GVC_CHECK_HIP(hipMalloc((void**)&c->r_dbg, (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long)));
-        GVC_CHECK_HIP(hipMemset(c->r_dbg, 0, (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long)));
+    if (getenv("GVC_PERSIST_STAMPS")) {        // diagnostics only: a failed allocation just leaves the stamps off
+        const size_t nb = (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long);
+        if (hipMalloc((void**)&c->r_dbg, nb) != hipSuccess || hipMemset(c->r_dbg, 0, nb) != hipSuccess) {
+            if (c->r_dbg) (void)hipFree(c->r_dbg);
+            c->r_dbg = nullptr;
+            (void)hipGetLastError();
+        }
     }
+    c->r_dirty.assign(L, 0);
     c->r_ready = 1;
     return GVC_OK;
 }
@@ -1306,16 +1338,18 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
     // cached positions on (default 144; 0: never), four beyond 320
     static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
-    const int key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
-                               ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
+    // (the prepare calls may switch a one-launch path off for this context -- r_ready / persist -- so they run before anything is
+    // derived from rows_decode_ok / persist_ok)
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     if (!persist_ok(c, B) && rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    const int key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
+                               ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
     const bool rows1 = !persist_ok(c, B) && c->r_ready == 1 && rows_persist_ok(c, B, c->st.seq_len);      // one-launch rows step
     c->rows_keys_hint = key_bound;
     const int key = B * 2 + (fused ? 1 : 0) + 4096 * (rows1 ? 8 + rows_persist_chunks(c, B, key_bound) : key_chunks);   // (the one-launch steps are pure functions of B [and the key split])
     c->last_variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1)));
     // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
-    static const int kStepUnroll = getenv("GVC_STEP_UNROLL") ? std::max(1, atoi(getenv("GVC_STEP_UNROLL"))) : 8;
+    static const int kStepUnroll = getenv("GVC_STEP_UNROLL") ? std::min(32, std::max(1, atoi(getenv("GVC_STEP_UNROLL")))) : 8;   // (<= 32: bits 24..29 of the graph key)
     // (the sampler kernel is chosen at capture time: a graph serves top_k = 1 or everything else)
     const bool greedy = sample_greedy_ok(p->top_k, c->dm.d_model);
     auto graph_of = [&](int unroll, hipGraphExec_t* ge) -> int {

@@ -174,14 +174,34 @@ struct HfConv { float *w = nullptr, *b = nullptr, *wp = nullptr; int Co = 0, Ci 
 struct HfUp { float *w = nullptr, *b = nullptr, *braw = nullptr, *wp = nullptr; int Ci = 0, Co = 0, k = 0, s = 0, pad = 0, dmin = 0, ntap = 0; };
 // a stage input: one buffer, or the nsum ResBlock planes (ss floats apart) whose scaled sum it is
 struct HfIn { const float* x = nullptr; int nsum = 1; long long ss = 0; float scale = 1.f; };
+constexpr int kHfRing = 4;
 struct HfPlan {
-    hipGraph_t graph = nullptr; hipGraphExec_t ge = nullptr;
+    hipGraph_t graph = nullptr;
+    // A ring of executable graphs of the same captured graph.  The caller's two pointers are patched into an executable graph, and a
+    // patch (or a destroy) must not touch one whose previous launch may still be in flight on the stream (streamed chunks are
+    // enqueued back to back without a host sync): each slot remembers the pointers it holds and an event recorded behind its last
+    // launch; a slot is only patched after that event has completed (normally long ago: the slot is the least recently launched).
+    hipGraphExec_t ge[kHfRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kHfRing] = {nullptr, nullptr, nullptr, nullptr};
+    const float* in[kHfRing] = {nullptr, nullptr, nullptr, nullptr};
+    float* wav[kHfRing] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long used[kHfRing] = {0, 0, 0, 0};
+    bool flying[kHfRing] = {false, false, false, false};
     HfIn out; int T = 0;                       // what conv_post reads
-    // whole-call graphs: the nodes that carry the caller's pointers, and the pointers the executable graph holds now
+    // whole-call graphs: the nodes that carry the caller's pointers
     hipGraphNode_t head = nullptr, post = nullptr;
     dim3 head_grid, head_block, post_grid, post_block; unsigned post_lds = 0;
-    const float* in = nullptr; float* wav = nullptr;
 };
+
+// executable graphs may have launches in flight: wait for them, then destroy
+static void hf_destroy_plan(HfPlan& pl) {
+    for (int i = 0; i < kHfRing; ++i) {
+        if (pl.ev[i]) { if (pl.flying[i]) (void)hipEventSynchronize(pl.ev[i]); (void)hipEventDestroy(pl.ev[i]); }
+        if (pl.ge[i]) (void)hipGraphExecDestroy(pl.ge[i]);
+    }
+    if (pl.graph) (void)hipGraphDestroy(pl.graph);
+    (void)hipGetLastError();
+}
 
 struct gvc_hifigan {
     gvc_hifigan_dims dm;
@@ -205,6 +225,7 @@ struct gvc_hifigan {
     // the chain between the input staging and conv_post only touches context buffers: it is captured once per
     // (B, frames) and replayed (a dozen launches of a few microseconds each are host-bound when launched eagerly)
     std::map<long long, HfPlan> graphs;
+    unsigned long long graph_tick = 0;       // launch counter (least-recently-launched choice in a plan's ring)
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
     // GVC_VOCODER_SMALL_CONV=0: every conv through the tiled GEMM, one launch per conv; 2: only the ResBlocks on k_conv_lds (conv_pre and
@@ -291,7 +312,7 @@ extern "C" int gvc_hifigan_create(const gvc_hifigan_dims* dims, gvc_hifigan** ou
 
 extern "C" int gvc_hifigan_destroy(gvc_hifigan* c) {
     if (!c) return GVC_OK;
-    for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
+    for (auto& kv : c->graphs) hf_destroy_plan(kv.second);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) hipFree(p);
     delete c;
@@ -522,7 +543,7 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
 // a node of an executable graph refused its new parameters: from now on only the conv chain is replayed from a graph
 static int hf_patch_failed(gvc_hifigan* c, int B, int T0, int head, const float* in, int n, int scale, float* wav, hipStream_t s) {
     (void)hipGetLastError();
-    for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
+    for (auto& kv : c->graphs) hf_destroy_plan(kv.second);
     c->graphs.clear();
     c->use_graph = 2;
     hf_head(c, head, in, B, T0, n, scale, s);
@@ -549,7 +570,7 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         if (c->graphs.size() >= 64) {          // bounded cache: the frame count of a non-streaming call varies freely
-            for (auto& kv : c->graphs) { hipGraphExecDestroy(kv.second.ge); hipGraphDestroy(kv.second.graph); }
+            for (auto& kv : c->graphs) hf_destroy_plan(kv.second);
             c->graphs.clear();
         }
         HfPlan pl;
@@ -560,7 +581,7 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
         hipError_t e = hipStreamEndCapture(c->cap_stream, &pl.graph);
         if (rc) { if (pl.graph) hipGraphDestroy(pl.graph); return rc; }
         GVC_CHECK_HIP(e);
-        e = hipGraphInstantiate(&pl.ge, pl.graph, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&pl.ge[0], pl.graph, nullptr, nullptr, 0);
         if (e != hipSuccess) hipGraphDestroy(pl.graph);
         GVC_CHECK_HIP(e);
         if (whole) {
@@ -580,12 +601,33 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
                 if (kp.func == post_fn) { pl.post = nd; pl.post_grid = kp.gridDim; pl.post_block = kp.blockDim; pl.post_lds = kp.sharedMemBytes; }
             }
             GVC_REQUIRE(pl.head && pl.post, GVC_ERR_STATE, "hifigan: the captured graph has no input / output kernel node");
-            pl.in = in; pl.wav = wav;
+            pl.in[0] = in; pl.wav[0] = wav;
         }
         it = c->graphs.emplace(key, pl).first;
     }
     HfPlan& pl = it->second;
-    if (whole && pl.in != in) {
+    // which executable graph: one that already holds the caller's pointers, else the least recently launched (instantiated on first
+    // use), patched once its previous launch has finished
+    int slot = -1;
+    if (whole) {
+        for (int i = 0; i < kHfRing && slot < 0; ++i)
+            if (pl.ge[i] && pl.in[i] == in && pl.wav[i] == wav) slot = i;
+        if (slot < 0) {
+            slot = 0;
+            for (int i = 1; i < kHfRing; ++i)
+                if (pl.used[i] < pl.used[slot]) slot = i;
+            if (!pl.ge[slot]) {
+                GVC_CHECK_HIP(hipGraphInstantiate(&pl.ge[slot], pl.graph, nullptr, nullptr, 0));
+                pl.in[slot] = nullptr;                                  // (a fresh instance holds the captured pointers: patch both)
+                pl.wav[slot] = nullptr;
+            }
+            if (pl.flying[slot]) { GVC_CHECK_HIP(hipEventSynchronize(pl.ev[slot])); pl.flying[slot] = false; }
+        }
+    } else {
+        slot = 0;
+    }
+    hipGraphExec_t ge = pl.ge[slot];
+    if (whole && pl.in[slot] != in) {
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
         kp.gridDim = pl.head_grid; kp.blockDim = pl.head_block;
@@ -595,10 +637,10 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
         void* a_cf[] = {&in, &x0, &d, &t0};
         kp.func = head == kHeadLatents ? reinterpret_cast<void*>(&k_interp_linear) : reinterpret_cast<void*>(&k_cf_to_time_major);
         kp.kernelParams = head == kHeadLatents ? a_lat : a_cf;
-        if (hipGraphExecKernelNodeSetParams(pl.ge, pl.head, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
-        pl.in = in;
+        if (hipGraphExecKernelNodeSetParams(ge, pl.head, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
+        pl.in[slot] = in;
     }
-    if (whole && pl.wav != wav) {
+    if (whole && pl.wav[slot] != wav) {
         hipKernelNodeParams kp;
         memset(&kp, 0, sizeof(kp));
         kp.gridDim = pl.post_grid; kp.blockDim = pl.post_block; kp.sharedMemBytes = pl.post_lds;
@@ -610,11 +652,17 @@ static int hf_run(gvc_hifigan* c, int B, int T0, int head, const float* in, int 
         void* a[] = {&x.x, &x.ss, &x.scale, &pw, &pb, &wav, &T, &C, &k, &slope};
         kp.func = x.nsum == 1 ? reinterpret_cast<void*>(&k_conv_post_tanh<1>) : reinterpret_cast<void*>(&k_conv_post_tanh<3>);
         kp.kernelParams = a;
-        if (hipGraphExecKernelNodeSetParams(pl.ge, pl.post, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
-        pl.wav = wav;
+        if (hipGraphExecKernelNodeSetParams(ge, pl.post, &kp) != hipSuccess) return hf_patch_failed(c, B, T0, head, in, n, scale, wav, s);
+        pl.wav[slot] = wav;
     }
-    GVC_CHECK_HIP(hipGraphLaunch(pl.ge, s));
-    if (whole) return GVC_OK;
+    GVC_CHECK_HIP(hipGraphLaunch(ge, s));
+    if (whole) {
+        if (!pl.ev[slot]) GVC_CHECK_HIP(hipEventCreateWithFlags(&pl.ev[slot], hipEventDisableTiming));
+        GVC_CHECK_HIP(hipEventRecord(pl.ev[slot], s));
+        pl.flying[slot] = true;
+        pl.used[slot] = ++c->graph_tick;
+        return GVC_OK;
+    }
     // round-2 scheme: staging before, conv_post after the graph (the staging kernel was enqueued by the caller of this branch)
     return hf_post(c, pl.out, B, pl.T, wav, s);
 }

@@ -212,6 +212,7 @@ class GPT(nn.Module):
         self._need_engine()
         kw = dict(generate_kwargs)
         group = kw.pop("group", 16)          # decode steps per engine call (one host look at the finished flags per call)
+        class_seeds = kw.pop("class_seeds", None)      # sampling runs: one seed per group (default: seed + 7919 * group index)
         budgets = kw.get("max_new_tokens")
         if isinstance(budgets, (list, tuple)):
             if len(budgets) != len(groups):
@@ -227,12 +228,14 @@ class GPT(nn.Module):
             if stats is not None and len(groups) > 1:
                 stats["separate"] += 1
             # one generate() per class; a sampling run gives every class its own random stream (the rows of one class keep the
-            # per-row numbering of the counter RNG): with one shared seed all classes would draw identical per-row sequences
+            # per-row numbering of the counter RNG): with one shared seed all classes would draw identical per-row sequences.
+            # Seed semantics: class gi of THIS call draws with class_seeds[gi] when the caller numbers its classes across calls
+            # (parallel_offline.convert_batch does: several calls per job), else with seed + 7919 * gi
             outs = []
             for gi, (c, t) in enumerate(groups):
                 kg = dict(kw)
                 if not greedy:
-                    kg["seed"] = int(kw.get("seed", 0)) + 7919 * gi
+                    kg["seed"] = int(class_seeds[gi]) if class_seeds is not None else int(kw.get("seed", 0)) + 7919 * gi
                 if budgets is not None:
                     kg["max_new_tokens"] = budgets[gi]
                 outs.append(self.generate(c, t, **kg))

@@ -51,7 +51,7 @@ def _n_segments(n_samples, seg):
 
 
 @torch.inference_mode()
-def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg=None, tokens_per_second=None, **gen_kwargs):
+def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg=None, tokens_per_second=None, utt_ids=None, **gen_kwargs):
     """Tokens of a micro-batch of utterances.  Segment s of the utterances that HAVE a segment s of the same length forms
     one class (same prefix length: all full segments of the batch, and equal-length tails), prefilled in one batched call;
     tails of other lengths are classes of their own -- never padded, which would change the reference's result
@@ -61,6 +61,9 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
     tokens_per_second (benchmark mode, SURVEY.md 8d: synthetic weights seldom emit the stop token): a class of segments of t seconds
     gets the fixed budget round(t * tokens_per_second) instead of max_new_tokens (23.4375: 141 tokens for 6 s, 94 for 4 s); a class
     whose budget is spent leaves the joint decode.
+    utt_ids: the utterances' indices in the whole job (default 0..B-1).  A sampling run seeds the class of segment s whose first row is
+    utterance u with seed + 7919 * (u * n_seg + s): distinct over all the generate_groups calls of a job (calls, waves and ranks),
+    not restarting at every call.
     Returns int32 [B, n_seg, max_len] padded with the stop token (also the rows of segments an utterance does not have)."""
     m = model
     stop = m.gpt.stop_audio_token
@@ -98,6 +101,8 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
         if tokens_per_second:
             cap = kw.get("max_new_tokens") or max_len
             kj["max_new_tokens"] = [max(1, min(cap, int(round(ns / m.content_sample_rate * tokens_per_second)))) for _, _, _, ns in classes[i:j]]
+        ids = list(range(B)) if utt_ids is None else list(utt_ids)
+        kj["class_seeds"] = [int(kw.get("seed", 0)) + 7919 * (ids[rows[0]] * n_seg + s) for s, rows, _, _ in classes[i:j]]
         gens = m.gpt.generate_groups([(cond_latent.expand(len(rows), -1, -1).contiguous(), codes) for _, rows, codes, _ in classes[i:j]], **kj)
         for (s, rows, _, _), gen in zip(classes[i:j], gens):
             out[rows, s, :gen.shape[1]] = gen.to(torch.int32)
@@ -106,9 +111,12 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
 
 
 @torch.inference_mode()
-def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank=0, world=1, group=None, **gen_kwargs):
+def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank=0, world=1, process_group=None, **gen_kwargs):
     """All utterances of the job (any lengths), sharded by rank (see plan), in waves of `micro_batch`; no collective while
-    converting, ONE all_gather of the padded token ids at the end.  Returns int32 [n_utts, n_seg, max_len] on every rank."""
+    converting, ONE all_gather of the padded token ids at the end.  Returns int32 [n_utts, n_seg, max_len] on every rank.
+    process_group: the torch.distributed group of the all_gather (default: the world).  Everything in gen_kwargs goes to
+    GPT.generate_groups -- including its `group` (decode steps per host look at the finished flags), which this function's
+    process-group parameter used to shadow: with `group=48` in the kwargs every N > 1 run died in the all_gather."""
     m = model
     cond = m.get_gpt_cond_latents(ref_audio.to(m.device), m.config.audio.sample_rate)
     lengths = [int(w.shape[-1]) for w in src_wavs]
@@ -119,5 +127,5 @@ def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank
     local = torch.full((len(mine), n_seg, max_len), m.gpt.stop_audio_token, dtype=torch.int32, device=m.device)
     for i in range(0, len(mine), micro_batch):
         wave = mine[i:i + micro_batch]
-        local[i:i + len(wave)] = convert_batch(m, [src_wavs[j] for j in wave], cond, seg_len, max_len, n_seg, **gen_kwargs)
-    return gather_token_ids(local, len(src_wavs), m.gpt.stop_audio_token, rank, world, group, lengths)
+        local[i:i + len(wave)] = convert_batch(m, [src_wavs[j] for j in wave], cond, seg_len, max_len, n_seg, utt_ids=wave, **gen_kwargs)
+    return gather_token_ids(local, len(src_wavs), m.gpt.stop_audio_token, rank, world, process_group, lengths)

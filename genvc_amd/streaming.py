@@ -20,8 +20,9 @@ ContentVec one segment at a time, so the first frames of every segment see no pa
 1.3 s, its attention the whole input, its layer-0 GroupNorm statistics the whole input).  With `left_context_s > 0` a stream keeps
 that many seconds of its already fed source audio (a multiple of 320 samples, ContentVec's hop) and extracts the features of
 [kept past | new segment], passing only the segment's frames on to the content tokeniser; frame i of the window starts at sample
-320 i, so the segment's frames are exactly the last ones.  The default (0) is the reference's behaviour.  With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in
-the call, not in the utterance.
+320 i, so the segment's frames are exactly the last ones.  The default (0) is the reference's behaviour.
+
+With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in the call, not in the utterance.
 """
 import torch
 
@@ -39,6 +40,8 @@ class _Session:
         self.prev = self.overlap = None
         self.tokens = []           # per segment: int64 [1, n]
         self.past = None           # left context: the tail of the source audio fed so far [1, <= ctx samples]
+        self.current = None        # the segment being decoded and its ContentVec left context as they were when it started (recovery)
+        self.skip = 0              # tokens of the current segment already emitted before a failed step (recovery re-run)
 
 
 class StreamSessions:
@@ -58,6 +61,7 @@ class StreamSessions:
         samp = dict(repetition_penalty=kw["repetition_penalty"], temperature=kw["temperature"], top_p=kw["top_p"], top_k=kw["top_k"])
         self.params = sample_params(samp, g.num_audio_tokens, g.stop_audio_token, 0)
         self.calls = 0
+        self.recoveries = 0          # decode calls dropped and re-run after a hand-off time-out (gvc_gpt_health)
         self.stop = g.stop_audio_token
         # per-slot history of input ids (fake prefix + generated), as wide as the longest run
         self.width = 32 + g.max_text_tokens + 2 + 1 + self.max_new + 8
@@ -120,6 +124,8 @@ class StreamSessions:
                 starts.setdefault((s.queue[0].shape[-1], s.prefilled), []).append(sid)
         for (n, cached), sids in starts.items():
             ss = [self.sessions[i] for i in sids]
+            for s in ss:
+                s.current = (s.queue[0], s.past)
             wav = torch.cat([s.queue.pop(0) for s in ss], 0)
             feat = self.segment_features(ss, wav)
             codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
@@ -153,11 +159,22 @@ class StreamSessions:
         self.params.seed = self.calls          # a fresh counter-RNG stream per call (only matters for top_k > 1)
         self.calls += 1
         eng.generate(slots, ids, ids_len, fin, self.params, 0, n, toks, lats, max_keys=W - 8)
+        th = toks.cpu()                                           # (synchronises: the steps above have run)
+        try:
+            eng.health()
+        except Exception:
+            # a hand-off of the one-launch step timed out (not all workgroups resident, e.g. another context on the GPU): these tokens
+            # and latents are garbage and so are the K/V rows the steps appended.  Nothing of this call is kept or vocoded; the library
+            # has switched the context to the launch-per-phase paths, on which the affected segments are decoded again from their start
+            self.recoveries += 1
+            for _, s in act:
+                self._requeue(s)
+            eng.reset(slots)
+            return out
         self.ids[idx, :W] = ids
         self.ids_len[idx] = ids_len
         self.finished[idx] = fin
-        th = toks.cpu()
-        keep = []
+        keep, emit = [], []
         for b, (sid, s) in enumerate(act):
             hit = (th[b] == self.stop).nonzero()
             nb = int(hit[0]) + 1 if hit.numel() else n            # the EOS step is part of the group (reference :189-196)
@@ -168,9 +185,12 @@ class StreamSessions:
                 s.decoding = False
                 s.tokens[-1] = torch.cat(s.tokens[-1], 1)
             keep.append(nb)
+            emit.append(s.done > s.skip)                          # (a recovery re-run: the groups emitted before the failure stay silent)
         # 3. vocoder, batched over equal group lengths
         for nb in sorted(set(keep)):
-            rows = [b for b in range(B) if keep[b] == nb]
+            rows = [b for b in range(B) if keep[b] == nb and emit[b]]
+            if not rows:
+                continue
             audio = _vocode(m, lats[rows, :nb].contiguous())
             if audio is None:
                 continue
@@ -178,4 +198,18 @@ class StreamSessions:
                 sid, s = act[b]
                 chunk, s.prev, s.overlap = handle_chunks(audio[j].squeeze(), s.prev, s.overlap, 1024)
                 out.setdefault(sid, []).append(chunk)
+        for _, s in act:
+            if not s.decoding:
+                s.skip = 0
         return out
+
+    def _requeue(self, s):
+        """put the segment a session was decoding back at the head of its queue, as it was when the segment started; the groups it has
+        already emitted (whole groups: a failed call emits nothing) are skipped by the re-run, so the stream's audio continues where
+        it stopped (greedy decoding repeats the tokens; the cross-fade state was only ever advanced by emitted chunks)"""
+        seg, past = s.current
+        s.skip = max(s.skip, s.done)
+        s.queue.insert(0, seg)
+        s.past = past
+        s.decoding, s.prefilled, s.done = False, False, 0
+        s.tokens.pop()

@@ -208,6 +208,31 @@ def test_hifigan_whole_call_graph_follows_the_callers_buffers(gold):
     eng.close()
 
 
+def test_hifigan_back_to_back_calls_without_sync_keep_their_own_buffers(gold):
+    """streamed chunks are enqueued back to back with no host sync in between, each with other input / output
+    pointers, so the executable graph of call N + 1 is prepared while call N may still be running.  A ring of executable graphs
+    (a slot is only re-pointed once its previous launch has finished) keeps every call on its own buffers: 24 calls with 6
+    different inputs and fresh outputs, enqueued in one go, each equal to the synchronous result"""
+    from genvc_amd.engine import HifiganEngine
+    g = gold("hifigan")
+    seed = int(g["seed"])
+    c = gcfg.DEFAULT_VOCODER
+    eng = HifiganEngine(c, max_batch=2, max_frames=64)
+    eng.bind(synth.make_weights(seed, synth.hifigan_weight_spec(c), device=DEV))
+    lat0 = synth.uniform(seed, "lat_1_8", (1, 8, c["input_feat_dim"]), 1.0).to(DEV)
+    lats = [(lat0 * (1.0 - 0.1 * i)).contiguous() for i in range(6)]
+    sync = []
+    for x in lats:
+        sync.append(eng.forward_latents(x, 4).clone())
+        torch.cuda.synchronize()
+    np.testing.assert_allclose(sync[0].cpu().numpy(), g["full_wav_1_8"], atol=1e-4)
+    outs = [eng.forward_latents(lats[i % 6], 4) for i in range(24)]            # no sync: 24 graph launches in flight / queued
+    torch.cuda.synchronize()
+    for i, w in enumerate(outs):
+        assert torch.equal(w, sync[i % 6]), f"call {i} saw another call's buffers"
+    eng.close()
+
+
 def test_resampler_matches_oracle_restatement():
     """row f2: the polyphase sinc resampler kernel against the ORACLE's float64 restatement of torchaudio.functional.resample
     (oracle/genvc_oracle.py resample; torchaudio is absent from the image, so parity with torchaudio itself is unpinned)"""

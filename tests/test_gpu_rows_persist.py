@@ -83,13 +83,14 @@ def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n):
     eng.close()
 
 
-@pytest.mark.parametrize("B,Tc", [(1, 13), (1, 5), (2, 5)], ids=["16rows_one_stream", "8rows_one_stream", "16rows_two_streams"])
-def test_rows_step_cached_chunk_prefill_vs_full_prefill_and_oracle(B, Tc):
+@pytest.mark.parametrize("B,Tc,L", [(1, 13, 2), (1, 5, 2), (2, 5, 2), (1, 13, 30)],
+                         ids=["16rows_one_stream", "8rows_one_stream", "16rows_two_streams", "16rows_one_stream_30_layers"])
+def test_rows_step_cached_chunk_prefill_vs_full_prefill_and_oracle(B, Tc, L):
     """the <= 16 uncached rows of a streaming chunk (conditioning rows still in the KV cache): causal attention over the cached
     prefix plus the new rows of the same stream, against the same prefill computed in full on fresh slots and against the oracle;
     the decode steps that follow read the K/V rows the one-launch step appended"""
     from oracle import genvc_oracle as O
-    dims, w, eng = _engine(WIDE2, 3, 8)
+    dims, w, eng = _engine(dict(WIDE2, gpt_layers=L), 3, 8)
     wc = {k: v.cpu() for k, v in w.items()}
     dev = "cuda"
     cond = synth.uniform(91, "cond_latents", (B, 32, dims["d_model"]), 1.0)
@@ -199,6 +200,39 @@ def test_hand_off_timeout_falls_back_to_launch_per_phase(B, monkeypatch):
     ref_t, ref_l, _ = O.generate(wc, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
     assert torch.equal(toks.long(), ref_t)
     np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=1e-4)
+    eng.close()
+
+
+def test_rebind_repacks_the_rows_step_weights():
+    """the one-launch rows step streams its own packed copy of the block matrices, built on first use.  A second
+    bind() on the same context (GptEngine.bind is public and re-callable) must rebuild it: 2 streams generate with weights A, the
+    context is re-bound to weights B, and the same call must give B's oracle result (not A's) on the rows step"""
+    from test_gpu_gpt import run_generate
+    from oracle import genvc_oracle as O
+    dims, wa, eng = _engine(WIDE2, 3, 8)
+    wb = synth.make_weights(41, synth.gpt_weight_spec(dims), device="cuda")
+    cond = synth.uniform(5, "cond", (2, 32, 1024), 1.0)
+    codes = synth.integers(5, "codes", (2, 11), 256)
+    n = 8
+    _, ta, la = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() == 5
+    eng.bind(wb)
+    _, tb, lb = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() == 5                          # (the step graph captured with weights A is replayed: same packed buffer)
+    ref_t, ref_l, _ = O.generate({k: v.cpu() for k, v in wb.items()}, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    assert torch.equal(tb.long(), ref_t) and not torch.equal(tb, ta)
+    np.testing.assert_allclose(lb.numpy(), ref_l.numpy(), atol=1e-4)
+    # ... and the cached chunk prefill (the other user of the pack): re-bind back to A, prefill 16 uncached rows, compare with the oracle
+    eng.bind(wa)
+    dev = "cuda"
+    s1 = torch.zeros(1, device=dev, dtype=torch.int32)
+    pa = eng.prefix_embeddings(cond[:1].to(dev), codes[:1].to(dev).int())
+    eng.prefill(s1, pa, want_outputs=False)
+    codes_b = synth.integers(6, "codes_b", (1, 13), 256)
+    lg, lat = eng.prefill(s1, eng.prefix_embeddings(cond[:1].to(dev), codes_b.to(dev).int()), n_cached=32)
+    wac = {k: v.cpu() for k, v in wa.items()}
+    z, logits, _ = O.gpt_prefill(wac, dims, O.compute_embeddings(wac, dims, cond[:1], codes_b)[0])
+    np.testing.assert_allclose(lg.cpu().numpy(), logits.numpy(), atol=1e-4)
     eng.close()
 
 

@@ -143,6 +143,47 @@ def test_harnesses_match_the_oracle_driven_through_the_same_segmentation():
     _m.clear()
 
 
+def test_headline_chain_full_size_vs_oracle():
+    """the EXACT chain bench.py times, at GenVC_small's size (L = 30, d = 1024): synthesize_utt_streaming(seg_len=1.0,
+    stream_chunk_size=8) on a 3 s source = per 1 s chunk ContentVec -> DVAE/VQ -> prefix -> prefill (chunk 1: 48 rows; chunks 2, 3:
+    the 16 uncached rows on the one-launch rows step, conditioning rows cached) -> 24 one-launch decode steps -> vocoder per 8
+    tokens -> cross-fade (reference inference/inference_utils.py:135-217), against the ORACLE driven through the same harness.
+    The source seed is margin-screened on the CPU (python tests/chain_oracle.py: every greedy decision of the oracle has a
+    top-1 / top-2 gap > 2e-3 and every codebook decision a gap > 1e-2), as the reference fixtures are; the screen is re-asserted."""
+    from chain_oracle import streaming_chain, synthetic_bundle
+    from genvc_amd.inference.inference_utils import synthesize_utt_streaming
+    from genvc_amd.inference.model_init import model_init_synthetic
+    _m.clear()
+    torch.cuda.empty_cache()
+    cfg = gcfg.default_config()
+    m = model_init_synthetic(cfg, seed=1, device=DEV)[0]
+    m.config.top_k = 1
+    m.gpt.max_gen_mel_tokens = 24                                  # bench.py's fixed budget: 23 tokens + the EOS step per 1 s chunk
+    W = synthetic_bundle(cfg, 1, 24)
+    src = synth.synth_audio(402, "src", 48000)
+    ref = synth.synth_audio(100, "ref", 72000)
+    ex = streaming_chain(W, src, ref, 1.0, 8)
+    assert ex["token_margin"] > 2e-3 and ex["vq_margin"] > 1e-2, (ex["token_margin"], ex["vq_margin"])
+    eng = m.gpt.engine
+    before = eng.rows_step_launches()
+    st = synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
+    assert eng.rows_step_launches() - before == 2, "chunks 2 and 3 were not prefilled on the one-launch rows step"
+    assert eng.decode_variant() == 3, "the decode steps did not run on the one-launch step"
+    assert [t.shape[1] for t in st["tokens"]] == [t.shape[1] for t in ex["tokens"]] == [8] * 9       # same group boundaries
+    assert torch.equal(torch.cat(st["tokens"], 1).cpu(), torch.cat(ex["tokens"], 1))
+    np.testing.assert_allclose(torch.cat(st["latents"], 1).cpu().numpy(), torch.cat(ex["latents"], 1).numpy(), atol=2e-4)
+    assert st["wav"].shape == ex["wav"].shape == (9 * 7168,)
+    np.testing.assert_allclose(st["wav"].cpu().numpy(), ex["wav"].numpy(), atol=1e-3)
+    # the stages in front of the GPT, one by one
+    np.testing.assert_allclose(m.get_gpt_cond_latents(ref.to(DEV), 24000).cpu().numpy(), ex["cond"].numpy(), atol=2e-4)
+    for c in range(3):
+        feat = m.content_extractor.extract_content_features(src[:, c * 16000:(c + 1) * 16000].to(DEV))
+        np.testing.assert_allclose(feat.cpu().numpy(), ex["feats"][c].numpy(), atol=5e-4)
+        assert torch.equal(m.content_dvae.get_codebook_indices(feat.transpose(1, 2)).cpu(), ex["codes"][c])
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_long_latent_sequences_are_vocoded_in_windows():
     """the reference's non-streaming path vocodes the latents of ALL segments in one call (inference_utils.py:79-87): inputs
     beyond the engine's buffers run through overlapping windows and equal the one-shot oracle"""
@@ -327,6 +368,8 @@ def test_stream_sessions_scheduler_matches_solo_conversions():
         if steps > 3 and ss.idle():
             break
         assert steps < 200
+    from oracle import genvc_oracle as O
+    W = oracle_bundle(m, 30)
     for i, sid in enumerate(sids):
         solo = synthesize_utt_streaming(m, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
         toks = ss.close(sid)
@@ -336,7 +379,58 @@ def test_stream_sessions_scheduler_matches_solo_conversions():
         w = torch.cat(wavs[sid], -1)
         assert w.shape == solo["wav"].shape
         np.testing.assert_allclose(w.cpu().numpy(), solo["wav"].cpu().numpy(), atol=2e-4)
+        # ... and the parity bar proper: every session against the ORACLE's streaming conversion of its utterance (reference
+        # inference/inference_utils.py:135-217 on the oracle's stages), whatever the other sessions were doing in the shared steps
+        ex = O.synthesize_utt_streaming(W, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8)
+        assert torch.equal(mine, torch.cat(ex["tokens"], 1)[0]), f"stream {i}: tokens differ from the oracle"
+        assert w.shape == ex["wav"].shape
+        np.testing.assert_allclose(w.cpu().numpy(), ex["wav"].numpy(), atol=1e-3)
     _m.clear()
+
+
+def test_stream_sessions_recover_from_a_hand_off_timeout(monkeypatch):
+    """a hand-off time-out of the one-launch rows step (simulated: the grid is launched one workgroup short) leaves
+    garbage tokens / latents / K-V rows behind.  StreamSessions checks the context's health right after the synchronisation of a
+    decode call, emits nothing of a failed call, puts the affected segments back and decodes them again on the launch-per-phase
+    paths: both streams still end with the tokens and waveform of their solo conversions, nothing emitted twice."""
+    from genvc_amd.inference.inference_utils import segments, synthesize_utt_streaming
+    from genvc_amd.inference.model_init import model_init_synthetic
+    from genvc_amd.streaming import StreamSessions
+    _m.clear()
+    torch.cuda.empty_cache()
+    cfg = gcfg.default_config(tiny=True)
+    cfg.model_args.gpt_n_model_channels = 1024            # the width the one-launch steps serve (d = 1024, 4 heads), two layers
+    cfg.vocoder_config.input_feat_dim = 1024
+    m = model_init_synthetic(cfg, seed=3, device=DEV)[0]
+    m.config.top_k = 1
+    m.gpt.max_gen_mel_tokens = 24
+    refs = [synth.synth_audio(60 + i, "ref", 72000) for i in range(2)]
+    srcs = [synth.synth_audio(80 + i, "src", 32000) for i in range(2)]
+    solo = [synthesize_utt_streaming(m, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True) for i in range(2)]
+    ss = StreamSessions(m, max_sessions=4, group=8)
+    sids = [ss.open(r) for r in refs]
+    for i, sid in enumerate(sids):
+        for sg in segments(srcs[i], 16000, 5120):
+            ss.push(sid, sg)
+    wavs, steps = {}, 0
+    while not ss.idle():
+        if steps == 1:
+            monkeypatch.setenv("GVC_PERSIST_TEST_GRID", "255")          # the second decode call of the first segments fails
+        for sid, chunks in ss.step().items():
+            wavs.setdefault(sid, []).extend(chunks)
+        if steps == 1:
+            monkeypatch.delenv("GVC_PERSIST_TEST_GRID")
+        steps += 1
+        assert steps < 100
+    assert ss.recoveries == 1
+    for i, sid in enumerate(sids):
+        mine = torch.cat(ss.close(sid), 1)[0].cpu()
+        assert torch.equal(mine, torch.cat(solo[i]["tokens"], 1)[0].cpu()), f"stream {i}: tokens differ after the recovery"
+        w = torch.cat(wavs[sid], -1)
+        assert w.shape == solo[i]["wav"].shape
+        np.testing.assert_allclose(w.cpu().numpy(), solo[i]["wav"].cpu().numpy(), atol=2e-4)
+    del m
+    torch.cuda.empty_cache()
 
 
 def test_short_tail_segment_is_zero_padded_like_the_reference():
@@ -465,9 +559,22 @@ def test_stream_sessions_left_context_contentvec():
         assert torch.equal(f, m.content_extractor.extract_content_features(sg))
     ss_all, fa = run(10.0)
     n_seg = f0[0].shape[1]
+    from oracle import genvc_oracle as O
+    W = oracle_bundle(m, 8)
     for i in range(1, 4):
         pre = m.content_extractor.extract_content_features(src[:, :(i + 1) * sr])
         np.testing.assert_allclose(fa[i].cpu().numpy(), pre[:, pre.shape[1] - n_seg:].cpu().numpy(), atol=1e-5)
+        # the parity bar proper: the ORACLE's ContentVec (reference layers/content_processor.py:17-31) on [kept past | segment],
+        # last n_seg frames -- with the whole past kept that window is the utterance so far
+        ox = O.hubert_extract_features(W["hubert"], W["hubert_cfg"], src[:, :(i + 1) * sr].cpu())
+        np.testing.assert_allclose(fa[i].cpu().numpy(), ox[:, ox.shape[1] - n_seg:].numpy(), atol=5e-4)
+    # a bounded context (2 s): the window is [last 2 s of the past (whole hops) | segment]
+    _, f2o = run(2.0)
+    for i in range(1, 4):
+        lo = max(0, i * sr - 2 * sr)
+        lo += (i * sr - lo) % 320
+        ox = O.hubert_extract_features(W["hubert"], W["hubert_cfg"], src[:, lo:(i + 1) * sr].cpu())
+        np.testing.assert_allclose(f2o[i].cpu().numpy(), ox[:, ox.shape[1] - n_seg:].numpy(), atol=5e-4)
     # frames of segment i in the whole-utterance features: frame j of the utterance starts at sample 320 j
     def err(fs):
         e = []

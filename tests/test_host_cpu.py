@@ -228,6 +228,7 @@ class _StubModel:
         stop_audio_token, max_gen_mel_tokens = 1025, 12
         max_slots = 16                                                        # KV slots: bounds the streams of one joint decode
         calls = []
+        seen_kwargs = []
         group_calls = []                                                      # streams per class of every generate_groups call
 
         def generate(self, cond, codes, **kw):
@@ -237,6 +238,7 @@ class _StubModel:
             return (base + torch.arange(n)[None, :]) % 1024
 
         def generate_groups(self, groups, **kw):                             # the real one decodes the groups together
+            self.seen_kwargs.append(dict(kw))
             self.group_calls.append([int(t.shape[0]) for _, t in groups])
             assert sum(self.group_calls[-1]) <= self.max_slots or len(groups) == 1
             return [self.generate(c, t, **kw) for c, t in groups]
@@ -247,6 +249,7 @@ class _StubModel:
         self.gpt = self._Gpt()
         self.gpt.calls = []
         self.gpt.group_calls = []
+        self.gpt.seen_kwargs = []
 
     def get_gpt_cond_latents(self, audio, sr):
         return audio[:, :64].reshape(1, 32, 2)
@@ -264,7 +267,10 @@ def _offline_worker(rank, world, port, q):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     srcs, ref = _offline_job()
     m = _StubModel()
-    out = convert_offline(m, srcs, ref, seg_len=6.0, micro_batch=2, rank=rank, world=world)
+    # (`group` is generate_groups' "decode steps per host look", exactly as bench.py's offline leg passes it: it must reach the
+    # model and must not be mistaken for the process group of the all_gather)
+    out = convert_offline(m, srcs, ref, seg_len=6.0, micro_batch=2, rank=rank, world=world, group=48)
+    assert m.gpt.seen_kwargs and all(k.get("group") == 48 for k in m.gpt.seen_kwargs)
     q.put((rank, out.numpy(), len(m.gpt.calls), m.gpt.group_calls))
     dist.barrier()
     dist.destroy_process_group()
@@ -317,3 +323,36 @@ def test_convert_batch_packs_classes_by_kv_slots():
     assert torch.equal(a, b)
     assert len(big.gpt.group_calls) == 2 and len(small.gpt.group_calls) > 2
     assert all(sum(c) <= 2 or len(c) == 1 for c in small.gpt.group_calls)
+
+
+def test_bench_self_launches_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` (N > 1) with no launcher in the environment becomes `torch.distributed.run --nproc-per-node N` on
+    127.0.0.1 with the caller's flags; with fewer than N GPUs visible it refuses instead of running one process and printing
+    `n_gpus: 1` (missing item 1)."""
+    import importlib.util
+    import argparse
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_exec(exe, cmd, env):
+        seen["exe"], seen["cmd"], seen["env"] = exe, cmd, env
+        raise SystemExit(0)
+
+    monkeypatch.setattr(bench.os, "execvpe", fake_exec)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("GVC_BENCH_SAME_DEVICE", raising=False)
+    with pytest.raises(SystemExit):
+        bench.self_launch(argparse.Namespace(gpus=4))
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # too few GPUs: a loud refusal, not a silent 1-process run
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(argparse.Namespace(gpus=4))
+    assert "only 1 GPU" in str(e.value)
