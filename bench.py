@@ -223,13 +223,13 @@ def offline_leg(wl, rank, world, dist, device):
     # fixed token budgets by segment duration (23.4375 tokens per second: 141 for the 6 s class, 94 for the 4 s class)
     kw = dict(seg_len=6.0, top_k=1, max_new_tokens=141, tokens_per_second=23.4375, group=int(os.environ.get("GVC_BENCH_OFFLINE_GROUP", "48")))     # decode steps between two host looks at the finished flags (library default 16: +0.5 %)
 
-    def run(mb, r, w):
-        convert_offline(m, srcs[:mb * w], ref, micro_batch=mb, rank=r, world=w, **kw)        # graph capture / warm-up, one wave
+    def run(mb, r, w, rolling=False):
+        convert_offline(m, srcs[:mb * w], ref, micro_batch=mb, rank=r, world=w, rolling=rolling, **kw)        # graph capture / warm-up, one wave
         torch.cuda.synchronize()
         if dist is not None and w > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        toks = convert_offline(m, srcs, ref, micro_batch=mb, rank=r, world=w, **kw)          # ONE all_gather at its end
+        toks = convert_offline(m, srcs, ref, micro_batch=mb, rank=r, world=w, rolling=rolling, **kw)          # ONE all_gather at its end
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None and w > 1:
@@ -240,7 +240,8 @@ def offline_leg(wl, rank, world, dist, device):
         return OFFLINE_UTTS / dt
 
     m.gpt.groups_stats = {"joint": 0, "separate": 0}
-    rate = run(OFFLINE_MICRO_BATCH, rank, world)
+    rate_waves = run(OFFLINE_MICRO_BATCH, rank, world)                     # one joint decode per micro-batch, drained to its longest class
+    rate = run(OFFLINE_MICRO_BATCH, rank, world, rolling=True)             # the same 16 streams per step, kept full across micro-batches
     stats = dict(m.gpt.groups_stats)
     variant = wl.eng.decode_variant()
     # the micro-batch must have been decoded JOINTLY (its 6 s and 4 s classes in one step over 16 streams) on the multi-stream
@@ -251,7 +252,10 @@ def offline_leg(wl, rank, world, dist, device):
                        "only (BASELINE configs[2]); utterances sharded over the ranks, one all_gather of the token ids at the end",
            "micro_batch_utterances_per_gpu": OFFLINE_MICRO_BATCH, "n_gpus": world,
            "streams_per_decode_step": OFFLINE_SEGMENTS * OFFLINE_MICRO_BATCH, "joint_decodes": stats["joint"], "decode_variant": variant,
-           "offline_utts_per_s": rate}
+           "offline_utts_per_s": rate, "offline_utts_per_s_wave_by_wave": rate_waves,
+           "decode": "rolling: a (micro-batch, segment) class joins the 16-stream decode step when KV slots free up and leaves it when its "
+                     "token budget is spent (GPT.generate_rolling); `offline_utts_per_s_wave_by_wave` = one joint decode per micro-batch, "
+                     "drained to its 6 s class (round 3's figure).  With one micro-batch per rank (N = 8) the two coincide"}
     if world == 1:
         out["offline_utts_per_s_fully_batched_1gpu"] = run(OFFLINE_UTTS, 0, 1)
         out["note"] = ("a decode step streams the weights once whatever the batch: the fully batched figure is what one GPU can do, the "

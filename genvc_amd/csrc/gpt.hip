@@ -665,6 +665,13 @@ static int persist_test_grid() {
 typedef void (*persist_fn)(const PersistArgs);
 static persist_fn persist_kernel(const gvc_gpt* c) {
     const int nd = c->dm.d_model / 256;
+    // GVC_PERSIST_XCD=0: d_model 1024 keeps the device-wide hand-off of the hidden units (the round-3 kernel)
+    static const int xcd_local = getenv("GVC_PERSIST_XCD") ? atoi(getenv("GVC_PERSIST_XCD")) : 1;
+    if (nd == 4 && xcd_local) {
+        if (c->kv_bf16) return (persist_fn)k_decode_persist<4, 1, 1, 1>;
+        if (c->bf16) return (persist_fn)k_decode_persist<4, 1, 0, 1>;
+        return (persist_fn)k_decode_persist<4, 0, 0, 1>;
+    }
     if (c->kv_bf16) return nd == 4 ? (persist_fn)k_decode_persist<4, 1, 1> : (persist_fn)k_decode_persist<2, 1, 1>;
     if (c->bf16) return nd == 4 ? (persist_fn)k_decode_persist<4, 1, 0> : (persist_fn)k_decode_persist<2, 1, 0>;
     return nd == 4 ? (persist_fn)k_decode_persist<4> : nd == 3 ? (persist_fn)k_decode_persist<3> : nd == 2 ? (persist_fn)k_decode_persist<2>
@@ -706,7 +713,7 @@ static int persist_prepare(gvc_gpt* c) {
     };
     const size_t ngran = persist_granules(d, H);
     if (hipMalloc((void**)&c->p_gran, ngran * sizeof(pu64)) != hipSuccess || hipMemset(c->p_gran, 0, ngran * sizeof(pu64)) != hipSuccess ||
-        hipMalloc((void**)&c->p_epoch, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned)) != hipSuccess)
+        hipMalloc((void**)&c->p_epoch, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned)) != hipSuccess)
         return unavailable();
     if (getenv("GVC_PERSIST_STAMPS")) {
         const size_t nb = (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long);
@@ -753,6 +760,10 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.logits_out = logits_out; A.latent_out = latent_out; A.step_ctr = step_ctr; A.advance = 1;
     A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr; A.hvec_floats = c->p_hvec;
     A.dbg = c->p_dbg;
+    static const int poll_b = getenv("GVC_PERSIST_POLL_B") ? atoi(getenv("GVC_PERSIST_POLL_B")) : 3;
+    static const int poll_h = getenv("GVC_PERSIST_POLL_H") ? atoi(getenv("GVC_PERSIST_POLL_H")) : 3;
+    static const int loader_depth = getenv("GVC_PERSIST_LOADER_DEPTH") ? atoi(getenv("GVC_PERSIST_LOADER_DEPTH")) : 2;
+    A.poll_b = poll_b; A.poll_h = poll_h; A.loader_depth = loader_depth;
     if (c->bf16) A.head_w = reinterpret_cast<const float*>(c->head_h);
     void* kargs[] = {&A};
     GVC_CHECK_HIP(hipLaunchKernel((const void*)persist_kernel(c), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->p_lds, s));
@@ -766,7 +777,7 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
 // ---------------------------------------------------------------------------------------------
 static bool rows_persist_ok(const gvc_gpt* c, int rows, const int32_t* base_len) {
     return c->persist && c->persist_rows && c->r_ready >= 0 && base_len && rows >= c->persist_rows_min && rows <= kRMaxRows &&
-           c->dm.d_model == kRD && c->hd == kRHD && c->dm.n_head == 4 && c->dm.n_layer % 2 == 0 &&
+           c->dm.d_model == kRD && (c->hd == 64 || c->hd == 128 || c->hd == 256) && c->dm.n_head * c->hd == kRD && c->dm.n_layer % 2 == 0 &&
            c->n_cu >= kPG;
 }
 
@@ -775,8 +786,22 @@ static int rows_persist_chunks(const gvc_gpt* c, int rows, int keys) {
     (void)keys;                              // (the kernel picks the split from the contexts it finds; this is the bound)
     int nch = kRMaxChunks;
     const int R = rows <= 8 ? 8 : 16;
-    while (nch > 1 && R * c->dm.n_head * nch > kPG) nch >>= 1;
+    while (nch > 1 && R * (kRD / kRHD) * nch > kPG) nch >>= 1;       // (phase B's workgroups: one per row, 256-dim super-head and key chunk)
     return nch;
+}
+
+// the instantiation for this context: padded rows (8 / 16), weight / cache storage, real head_dim
+typedef void (*rows_fn)(const RowsArgs);
+template <int HDR>
+static const void* rows_kernel_hd(const gvc_gpt* c, int R) {
+    rows_fn f;
+    if (c->kv_bf16) f = R == 8 ? (rows_fn)k_rows_persist<8, 1, 1, HDR> : (rows_fn)k_rows_persist<16, 1, 1, HDR>;
+    else if (c->bf16) f = R == 8 ? (rows_fn)k_rows_persist<8, 1, 0, HDR> : (rows_fn)k_rows_persist<16, 1, 0, HDR>;
+    else f = R == 8 ? (rows_fn)k_rows_persist<8, 0, 0, HDR> : (rows_fn)k_rows_persist<16, 0, 0, HDR>;
+    return (const void*)f;
+}
+static const void* rows_kernel(const gvc_gpt* c, int R) {
+    return c->hd == 64 ? rows_kernel_hd<64>(c, R) : c->hd == 128 ? rows_kernel_hd<128>(c, R) : rows_kernel_hd<256>(c, R);
 }
 
 static void rows_persist_release(gvc_gpt* c) {
@@ -815,13 +840,10 @@ static int rows_persist_prepare(gvc_gpt* c) {
     }
     if (c->r_ready != 0) return GVC_OK;
     const int L = c->dm.n_layer;
-    c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + 3 * kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 16 + kPCW * 256) * sizeof(float) +
+    c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + 3 * kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 64 + kPCW * 256) * sizeof(float) +
                kCtlWords * sizeof(unsigned);
     int per_cu = 0;
-    const void* kern[2] = {nullptr, nullptr};      // the two instantiations (8 / 16 padded rows) of this context's storage types
-    if (c->kv_bf16) { kern[0] = (const void*)k_rows_persist<8, 1, 1>; kern[1] = (const void*)k_rows_persist<16, 1, 1>; }
-    else if (c->bf16) { kern[0] = (const void*)k_rows_persist<8, 1, 0>; kern[1] = (const void*)k_rows_persist<16, 1, 0>; }
-    else { kern[0] = (const void*)k_rows_persist<8, 0, 0>; kern[1] = (const void*)k_rows_persist<16, 0, 0>; }
+    const void* kern[2] = {rows_kernel(c, 8), rows_kernel(c, 16)};      // the two instantiations (8 / 16 padded rows) of this context's storage types and head_dim
     const int wsh = c->bf16 ? 1 : 0;
     if (hipFuncSetAttribute(kern[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
         hipFuncSetAttribute(kern[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->r_lds) != hipSuccess ||
@@ -869,20 +891,14 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     A.tok_in = tok_in; A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.mel_pos_idx = c->st.mel_pos; A.vocab = c->dm.vocab;
     static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
     A.poll_all = poll_all;
+    static const int rows_loader_depth = getenv("GVC_ROWS_LOADER_DEPTH") ? atoi(getenv("GVC_ROWS_LOADER_DEPTH")) : 2;
+    A.loader_depth = rows_loader_depth;
     // keys of a (row, head) over 2 / 4 workgroups: 8 rows from 80 / 160 cached positions (one 80-key pass per workgroup; 744 vs 766 us
     // per step at 48-112 keys, 815 vs 827 at 110-250), 16 rows from 128 / 288 (their chunk merge gathers 64 KB per chunk: 1068 vs 1104 us)
     A.split1 = c->r_split1 > 0 ? c->r_split1 : (rows <= 8 ? 80 : 128);
     A.split2 = c->r_split2 > 0 ? c->r_split2 : (rows <= 8 ? 160 : 288);
-    const dim3 grid(persist_test_grid()), block(kPThreads);
-#define GVC_ROWS_LAUNCH(WBv, KVBv)                                                                        \
-    do {                                                                                                  \
-        if (rows <= 8) hipLaunchKernelGGL((k_rows_persist<8, WBv, KVBv>), grid, block, c->r_lds, s, A);   \
-        else hipLaunchKernelGGL((k_rows_persist<16, WBv, KVBv>), grid, block, c->r_lds, s, A);            \
-    } while (0)
-    if (c->kv_bf16) GVC_ROWS_LAUNCH(1, 1);
-    else if (c->bf16) GVC_ROWS_LAUNCH(1, 0);
-    else GVC_ROWS_LAUNCH(0, 0);
-#undef GVC_ROWS_LAUNCH
+    void* kargs[] = {&A};
+    GVC_CHECK_HIP(hipLaunchKernel(rows_kernel(c, rows <= 8 ? 8 : 16), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->r_lds, s));
     GVC_LAUNCH_CHECK();
     c->r_launches += 1;
     return GVC_OK;
@@ -1000,7 +1016,7 @@ static int check_ready(gvc_gpt* c) {
         for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
         c->graphs.clear();
         if (c->r_bufs) (void)hipMemset(c->r_bufs, 0xff, rows_buf_bytes());
-        if (c->p_epoch) (void)hipMemset(c->p_epoch, 0, 4 * sizeof(unsigned));
+        if (c->p_epoch) (void)hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned));
         *c->seam_err_host = 0;
         c->fallbacks += 1;
         set_error("an in-kernel hand-off of a one-launch decode step timed out (code %d: were all 256 workgroups resident?); the outputs "

@@ -23,6 +23,16 @@
 // then the double-LayerNorm head.  Contexts of <= 80 keys (head_dim 256, <= 4 heads) fuse B and C (persist_fused_attn).
 // Every spin is bounded: on a timeout the workgroup sets *err, and the host raises
 // GVC_ERR_STATE on the next call.
+//
+// XL (round 4, d_model 1024): the hidden units of the MLP never leave their XCD.  A hand-off between workgroups that share an L2
+// costs 1.0 us idle / 2.6 us beside the weight stream when the producer uses PLAIN stores (they stay in the XCD's L2) and the
+// consumers sc1 loads, against 2.4 / 3.7 us for the device-wide write-through hand-off (scripts/ubench/seam_xcd.hip).  Which XCD a
+// workgroup runs on is read from the hardware (XCC_ID: the dispatcher deals workgroups round-robin but does not start every grid at
+// XCD 0) and its rank j among the XCD's 32 workgroups comes from an atomic counter per XCD -- with one workgroup per CU resident
+// every XCD holds exactly 32.  So phase D of workgroup (x, j) produces hidden units [512 x + 16 j, +16) and
+// phase E multiplies the XCD's 512 hidden units into ITS K-slice of mlp c_proj for output rows [32 j, +32): the 4096-wide h hand-off
+// (the dearest of the layer: 3.8 us) becomes a 512-wide XCD-local one, and x leaves phase E as eight partial planes (one per XCD)
+// that the next phase A adds in its gather (64 KB instead of 16 KB per workgroup: +0.5 us).
 #pragma once
 #include "gpt_kernels.h"
 
@@ -37,7 +47,7 @@ constexpr int kPU = 4;              // keys per lane group held in registers per
 constexpr int kPUF = 10;            // ... in the fused attention + projection phase (short contexts: kPUF * kPCW keys)
 constexpr unsigned kPSpinLimit = 400000;
 // LDS control words
-constexpr int kCtlFilled = 0, kCtlDone = 1, kCtlArrive = 1 + kPCW, kCtlAbort = 2 + kPCW, kCtlWords = 16;
+constexpr int kCtlFilled = 0, kCtlDone = 1, kCtlArrive = 1 + kPCW, kCtlAbort = 2 + kPCW, kCtlXcd = 3 + kPCW, kCtlWords = 16;
 
 typedef unsigned long long pu64;
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
@@ -59,16 +69,18 @@ struct PersistArgs {
     float* latent_out;              // [d]
     int32_t* step_ctr;              // nullable
     int advance;
-    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[4][d] | HH[4d] | X1[2][d]
-    unsigned* epoch;                // [0] step epoch, [1] arrival counter of the running step
+    pu64* gran;                     // granule buffers: Q[3d] | P[kPMaxChunks][d + 2H] | X0[4][d] | HH[4d] | X1[8][d] (2 planes used without XL)
+    unsigned* epoch;                // [0] step epoch, [1] arrival counter of the running step, [4..11] XL: workgroups seen per XCD (32 per launch)
     int* err;                       // device-visible host word: != 0 after a timeout
     int ring_slots;                 // power of two
     int hvec_floats, ascr_floats;
     unsigned long long* dbg;        // nullable: wall-clock stamps
+    int loader_depth;               // LDS-DMA fills in flight per loader wave (1..3; default 2)
+    int poll_b, poll_h;             // back-off (s_sleep argument class 0 / 1 / 3) between polls of the q|k|v gather and of the XCD-local h gather
 };
 
 // granules of the hand-off buffers (host: allocation size)
-static inline size_t persist_granules(int d, int H) { return (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + 4 * d + 4 * d + 2 * d; }
+static inline size_t persist_granules(int d, int H) { return (size_t)3 * d + (size_t)kPMaxChunks * (d + 2 * H) + 4 * d + 4 * d + 8 * d; }
 
 // Short contexts of the trained GenVC shape (head_dim 256, <= 4 heads): attention and the attn c_proj run as ONE phase --
 // workgroup (i, h) recomputes head h's attention (<= kPUF * kPCW keys, K/V rows from L2) and multiplies it into its rows of the
@@ -147,6 +159,13 @@ __device__ __forceinline__ void publish(__amdgpu_buffer_rsrc_t rs, int index, un
     __builtin_amdgcn_raw_buffer_store_b64(g, rs, index * 8, 0, 16);
 }
 
+// the same granule for consumers on the producer's own XCD: a plain store (it stays in the shared L2; readers use sc1 loads)
+__device__ __forceinline__ void publish_local(__amdgpu_buffer_rsrc_t rs, int index, unsigned tag, float v) {
+    pu32x2 g;
+    g.x = __float_as_uint(v); g.y = tag;
+    __builtin_amdgcn_raw_buffer_store_b64(g, rs, index * 8, 0, 0);
+}
+
 // Sweep of a phase input by the consumer waves.  The input has NP planes of n granules (a K-split producer publishes
 // one partial sum per plane; the value is their sum, plane 0 first); item t of plane p sits at granule base + p * n + t.
 // A lane reads TWO adjacent granules per load (16 bytes): lane (wave, lane) owns items 2 (wave * 64 + lane) + {0, 1} +
@@ -154,7 +173,7 @@ __device__ __forceinline__ void publish(__amdgpu_buffer_rsrc_t rs, int index, un
 // the other loads when its tags have arrived (everything is re-issued if a tag is still old); one- and two-load sweeps re-read
 // everything in every poll pass, which saves a round trip (measured: 612 vs 630 us per step at 110-250 keys).  n is a multiple of 128.
 template <int NJ, int NP>
-__device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code) {
+__device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code, int sleep = 3) {
     if (c.dead || c.wave * 128 >= n) return;         // a wave is all in or all out
     const int t0 = 2 * (c.wave * 64 + c.lane);
     const int voff = (base + t0) * 8;
@@ -185,7 +204,7 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
             }
         }
         if (!__any(bad != 0u)) break;
-        if (spin_fail(c, spins, code, 3)) return;
+        if (spin_fail(c, spins, code, sleep)) return;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -314,8 +333,8 @@ __device__ __forceinline__ float4 merge_chunks(PCtx& c, __amdgpu_buffer_rsrc_t g
 }
 
 // ---- loader wave: the workgroup's weight rows, phase after phase, into the ring ---------------------------------
-template <int ND, int WB>
-__device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, char* ring) {
+template <int ND, int WB, int XL>
+__device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, char* ring, int xx, int jj) {
     constexpr unsigned D = 256 * ND;
     const unsigned rmask = A.ring_slots - 1;
     const int rm = A.vocab / kPG, rem = A.vocab - rm * kPG;
@@ -330,6 +349,7 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
         unsigned bytes;
         unsigned kib_stride = 1024;                  // global bytes between consecutive KiB of the segment (contiguous rows)
         unsigned lane_off = c.lane * 16;             // this lane's 16 bytes inside a KiB of the segment
+        bool rowpair = false;                        // a row piece is TWO consecutive KiB (kib_stride then counts rows)
         auto wptr = [&](const float* w, size_t elems) { return reinterpret_cast<const char*>(w) + ((elems * 4) >> WB); };
         if (sgi < 4 * A.n_layer) {
             const PersistLayer& Ly = A.layers[sgi >> 2];
@@ -342,7 +362,14 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
                 if (WB) lane_off = (c.lane >> 5) * (D * 2) + (c.lane & 31) * 16;
             }
             else if (ph == 1) { base = wptr(Ly.proj_w, (size_t)c.wg * ND * D); bytes = (ND * D * 4) >> WB; }
-            else if (ph == 2) { base = wptr(Ly.fc_w, (size_t)c.wg * (4 * ND) * D); bytes = (4 * ND * D * 4) >> WB; }
+            else if (ph == 2) {
+                const int dwg = XL ? xx * 32 + jj : c.wg;          // XL: the XCD's workgroups own 512 consecutive hidden units
+                base = wptr(Ly.fc_w, (size_t)dwg * (4 * ND) * D); bytes = (4 * ND * D * 4) >> WB;
+            }
+            else if (XL) {       // rows [32 j, +32) x the XCD's K-slice [512 x, +512) of mlp c_proj: 2 KiB (bf16: 1 KiB) per row
+                base = wptr(Ly.p2_w, (size_t)(32 * jj) * (4 * D) + 512 * xx); bytes = (32 * 2048) >> WB;
+                kib_stride = (4 * D * 4) >> WB; rowpair = !WB;
+            }
             else { base = wptr(Ly.p2_w, (size_t)c.wg * ND * (4 * D)); bytes = (ND * 4 * D * 4) >> WB; }
         } else if (sgi == 4 * A.n_layer) {
             base = wptr(A.head_w, (size_t)c.wg * rm * D); bytes = (rm * D * 4) >> WB;
@@ -370,18 +397,28 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
             const unsigned n = (min((unsigned)kPSlot, bytes - off)) >> 10;
             const unsigned slot = __builtin_amdgcn_readfirstlane(fseq & rmask);
             char* dst = ring + slot * kPSlot;
-            const char* src = base + (size_t)(off >> 10) * kib_stride + lane_off;
-            if (n == 16) {           // thinned: at most this fill and the one before it in flight
+            const char* src = base + (size_t)(rowpair ? off >> 11 : off >> 10) * kib_stride + lane_off;
+            if (n == 16 && rowpair) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(i >> 1) * kib_stride + (i & 1) * 1024),
+                                                     (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
+                if (A.loader_depth >= 3) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (fseq) lds_st(c.ctl + kCtlFilled, fseq - 1); }
+                else if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
+                else { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq); }
+            } else if (n == 16) {    // thinned: at most this fill and the one before it in flight
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * kib_stride),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                lds_st(c.ctl + kCtlFilled, fseq);
+                if (A.loader_depth >= 3) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (fseq) lds_st(c.ctl + kCtlFilled, fseq - 1); }
+                else if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
+                else { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq); }
             } else {
 #pragma unroll 1
                 for (unsigned i = 0; i < n; ++i)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * kib_stride),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowpair ? src + (size_t)(i >> 1) * kib_stride + (i & 1) * 1024
+                                                                                                             : src + (size_t)i * kib_stride),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_st(c.ctl + kCtlFilled, fseq + 1);
@@ -394,9 +431,11 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
 }
 
 // ---- decode-step kernel --------------------------------------------------------------------------------------
-template <int ND, int WB = 0, int KVB = 0>      // d_model = 256 * ND; bf16 weight storage; bf16 KV cache
+template <int ND, int WB = 0, int KVB = 0, int XL = 0>      // d_model = 256 * ND; bf16 weight storage; bf16 KV cache; XCD-local MLP hand-off
 __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs A) {
+    static_assert(!XL || ND == 4, "the XCD-local MLP hand-off is laid out for d_model 1024 (8 XCDs x 32 workgroups)");
     constexpr int D = 256 * ND;
+    constexpr int NPX = XL ? 8 : 2;              // planes of X1 (x as it leaves phase E): one per XCD, or the two K-halves
     constexpr int KSC = ND % 2 == 0 ? 2 : 1;     // K-split of an attn c_proj row over waves (partial sums = planes of X0)
     constexpr int KSE = 2;                       // K-split of an mlp c_proj row (planes of X1)
     constexpr int NJX = (D + kPCW * 128 - 1) / (kPCW * 128);        // 16-byte loads per lane and plane in a sweep over a d-vector
@@ -409,6 +448,13 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
     float* ascr = xvec + D;                      // attention: q_h | k_h | v_h of this step, then m_s, l_s
     unsigned* ctl = reinterpret_cast<unsigned*>(ascr + A.ascr_floats);
     if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0u;
+    // XL: this workgroup's XCD and its rank among the XCD's workgroups (requested here, used after the barrier)
+    unsigned xcc = 0, xrank = 0;
+    if (XL && threadIdx.x == kPCW * 64) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        xrank = __hip_atomic_fetch_add(A.epoch + 4 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
 
     PCtx c;
@@ -417,7 +463,13 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
     const unsigned epoch = __hip_atomic_load(A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (c.wave == kPCW) {
-        persist_loader<ND, WB>(A, c, ring);
+        int xx = 0, jj = 0;
+        if (XL) {
+            xx = __builtin_amdgcn_readfirstlane((int)xcc);
+            jj = __builtin_amdgcn_readfirstlane((int)(xrank & 31u));
+            if (c.lane == 0) lds_st(ctl + kCtlXcd, 0x10000u | (unsigned)(xx << 8) | (unsigned)jj);
+        }
+        persist_loader<ND, WB, XL>(A, c, ring, xx, jj);
     } else {
         // `lane` is re-defined through an empty asm at every phase: without it the compiler hoists the per-lane addresses of all
         // phases out of the layer loop and spills them to scratch (vector memory behind the loader's DMA queue)
@@ -440,7 +492,16 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const int PS = D + 2 * H;                        // granules per key chunk: o[D] | {m, l}[H]
         // granule indices of the five hand-off buffers inside the allocation
         const int iQ = 0, iP = 3 * D, iX0 = iP + kPMaxChunks * PS, iH = iX0 + 4 * D, iX1 = iH + 4 * D;
-        const __amdgpu_buffer_rsrc_t grs = make_rsrc(A.gran, (unsigned)(iX1 + 2 * D) * 8u);
+        const __amdgpu_buffer_rsrc_t grs = make_rsrc(A.gran, (unsigned)(iX1 + 8 * D) * 8u);
+        int xx = 0, jj = 0;              // XL: XCD and rank inside it (the loader wave publishes them through LDS)
+        auto need_xcd = [&]() {
+            if (!XL || xx >= 0x100) return;
+            unsigned v = 0, spins = 0;
+            while (!c.dead && !((v = lds_ld(ctl + kCtlXcd)) & 0x10000u))
+                if (spin_fail(c, spins, 960, 1)) break;
+            xx = (int)((v >> 8) & 7u) | 0x100;       // (bit 8: known)
+            jj = (int)(v & 31u);
+        };
         const unsigned tbase = ((epoch + 1u) & 0xfffffu) << 12;
         auto tag_of = [&](int l, int p) { return tbase | (unsigned)(l * 8 + p + 1); };
         // stamps (GVC_PERSIST_STAMPS): workgroup 0, every layer: [(l * 5 + p) * 4 + k], k = 0 input ready, 1 output published,
@@ -478,7 +539,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int nmy = wave < RA ? (RA - wave + kPCW - 1) / kPCW : 0;
                 const int row_g = wg * RA + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.qkv_b[row_g] : 0.f;
-                if (l > 0) gather<NJX, KSE>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l);
+                if (l > 0) gather<NJX, NPX>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l);
                 cbar(c);
                 stamp_at(l, 0, 0);
                 float val = 0.f;
@@ -694,7 +755,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     while (true) {
                         v = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
                         if (__all(v.y == tg && v.w == tg)) break;
-                        if (spin_fail(c, spins, 200 + l, 3)) break;
+                        if (spin_fail(c, spins, 200 + l, A.poll_b)) break;
                     }
                     *reinterpret_cast<float2*>(ascr + t) = make_float2(__uint_as_float(v.x), __uint_as_float(v.z));
                 }
@@ -809,7 +870,9 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 load_gb<ND>(Ly.ln2_w, Ly.ln2_b, lane, g, b);
                 constexpr int RD = 4 * ND, UPW = (RD + kPCW - 1) / kPCW;
                 const int nmy = wave < RD ? (RD - wave + kPCW - 1) / kPCW : 0;
-                const int row_g = wg * RD + wave + kPCW * lane;
+                need_xcd();
+                const int dwg = XL ? (xx & 7) * 32 + jj : wg;                // XL: hidden units [512 x + 16 j, +16) of XCD x
+                const int row_g = dwg * RD + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.fc_b[row_g] : 0.f;
                 if (!fused) gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
@@ -832,11 +895,43 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                         if (lane == i) val = s;
                     }
                 }
-                if (lane < nmy) publish(grs, iH + row_g, tag_of(l, 3), gelu_new(val + bias));
+                if (lane < nmy) {
+                    if (XL) publish_local(grs, iH + row_g, tag_of(l, 3), gelu_new(val + bias));       // read by this XCD's workgroups only
+                    else publish(grs, iH + row_g, tag_of(l, 3), gelu_new(val + bias));
+                }
                 fs += nfD;
                 phase_done();
                 stamp_at(l, 3, 1);
             }
+            // =================== E (XL): the XCD's 512 hidden units x its K-slice of mlp c_proj, 32 output rows -> plane x of X1 ===================
+            if constexpr (XL != 0) {
+                GVC_PHASE_BEGIN();
+                const int x8 = xx & 7;
+                const int orow = 32 * jj + 4 * wave + lane;                  // (lanes 0..3: the wave's four rows)
+                const float bias = x8 == 0 && lane < 4 ? Ly.p2_b[orow] : 0.f;
+                gather<1, 1>(c, grs, iH + 512 * x8, 512, tag_of(l, 3), hvec, 500 + l, A.poll_h);       // one 16-byte load per lane of waves 0..3
+                cbar(c);
+                stamp_at(l, 4, 0);
+                float4 hv[2];
+                vec_from_lds<2>(hvec, lane, hv);
+                wait_fill(c, fs + (((unsigned)(4 * wave + 3) * 2048u + 2047u) >> FSH));
+                float part[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) part[i] = row_partial<2, WB>(ring, rmask, fs, (unsigned)(4 * wave + i) * 2048u, lane, hv);
+                float val = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sm = wave_sum(part[i]);
+                    if (lane == i) val = sm;
+                }
+                if (lane < 4) {
+                    if (x8 == 0) val = xvec[orow] + (val + bias);            // plane 0 carries the residual (x' is still in xvec) and the bias
+                    publish(grs, iX1 + x8 * D + orow, tag_of(l, 4), val);
+                }
+                fs += nfD;
+                phase_done();
+                stamp_at(l, 4, 1);
+            } else
             // =================== E: mlp c_proj (row, K-half) units -> x = x' + ... ===================
             {
                 GVC_PHASE_BEGIN();
@@ -874,7 +969,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             const float bias = lane < nmy ? A.head_b[row_g] : 0.f;
             const bool tail = wave == kPCW - 1 && wg < rem;
             const float tbias = tail ? A.head_b[rm * kPG + wg] : 0.f;
-            gather<NJX, KSE>(c, grs, iX1, D, tag_of(L - 1, 4), xvec, 600);
+            gather<NJX, NPX>(c, grs, iX1, D, tag_of(L - 1, 4), xvec, 600);
             cbar(c);
             stamp_at(L, 0, 0);
             vec_from_lds<ND>(xvec, lane, xv);

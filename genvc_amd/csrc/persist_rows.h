@@ -24,7 +24,10 @@
 //     publishes of every workgroup that are younger than that workgroup's poison of layer l + 1.
 // Per layer: A [LN1, c_attn -> q|k|v rows, k/v appended to the cache] -> B [attention of one (row, head, key chunk) per
 // workgroup] -> C [merge of the chunk partials, attn c_proj, residual] -> D [LN2, c_fc, gelu_new] -> E [mlp c_proj, residual].
-// The head (double LayerNorm + mel_head) stays with the caller's launches.  d_model 1024, head_dim 256, an even layer count.
+// The head (double LayerNorm + mel_head) stays with the caller's launches.  d_model 1024, an even layer count; head_dim 256, 128 or 64
+// (4, 8 or 16 heads -- the reference's config default is 16, configs/genVC_configs.py:132): phase B works on "super-heads" of 256
+// consecutive model dims = 256 / head_dim real heads side by side in a wave (lanes of a head reduce among themselves, the softmax state
+// is per lane), so the workgroup mapping and every hand-off layout are those of the 4 x 256 case.
 #pragma once
 #include <type_traits>
 
@@ -32,7 +35,8 @@
 
 namespace gvc {
 
-constexpr int kRD = 1024, kRHD = 256;
+constexpr int kRD = 1024, kRHD = 256;           // kRHD: dims of a super-head (one workgroup of phase B)
+constexpr int kRMaxHeads = 16;
 constexpr unsigned kRPoison = 0xffffffffu;
 constexpr int kRWgLayerBytes = 192 * 1024;        // packed weights per workgroup and layer: 12 ring fills
 constexpr int kRMaxChunks = 4;                    // key chunks per (row, head)
@@ -40,8 +44,8 @@ constexpr int kRMaxRows = 16;
 // hand-off buffers (floats inside one parity), sized for 16 rows
 constexpr int kRoffQKV = 0;
 constexpr int kRoffOP = kRoffQKV + kRMaxRows * 3 * kRD;                       // [chunk][frag of R x D]
-constexpr int kRoffML = kRoffOP + kRMaxChunks * kRMaxRows * kRD;              // [chunk][row][head] float4 {m, l, 0, 0}
-constexpr int kRoffX0 = kRoffML + kRMaxChunks * kRMaxRows * 4 * 4;
+constexpr int kRoffML = kRoffOP + kRMaxChunks * kRMaxRows * kRD;              // [chunk][row][head (16 slots)] float4 {m, l, 0, 0}
+constexpr int kRoffX0 = kRoffML + kRMaxChunks * kRMaxRows * kRMaxHeads * 4;
 constexpr int kRoffHH = kRoffX0 + kRMaxRows * kRD;
 constexpr int kRoffX1 = kRoffHH + kRMaxRows * 4 * kRD;
 constexpr int kRParFloats = kRoffX1 + 2 * kRMaxRows * kRD;        // X1: two K-half planes of the mlp c_proj (their sum is x)
@@ -71,6 +75,7 @@ struct RowsArgs {
     int ring_slots, nchunks;        // nchunks: upper bound of the key split (the kernel picks 1 / 2 / 4 from the longest context it finds)
     int split1, split2;             // cached positions from which the keys of a (row, head) take 2 / 4 workgroups
     int poll_all;                   // gathers of up to this many 16-byte pieces per lane re-request everything in every poll pass
+    int loader_depth;               // LDS-DMA fills in flight per loader wave (1 or 2)
     unsigned long long* dbg;
 };
 
@@ -195,9 +200,10 @@ __device__ __forceinline__ void rgather2(PCtx& c, __amdgpu_buffer_rsrc_t rs, int
 
 // NC key chunks of NL pieces each plus their {m, l} pieces in ONE round trip: a sentinel piece is polled, then everything is requested
 // together (what is still poison is re-requested)
+// (ml2 / mloff2: the {m, l} of the head of the wave's LAST steps -- with head_dim 64 a wave's K-slice spans two heads)
 template <int NC, int NL>
-__device__ __forceinline__ void rgather_chunks(PCtx& c, __amdgpu_buffer_rsrc_t rs, int off, int stride, int coff, int mloff, int mlcoff,
-                                               pu32x4 (&v)[NC][NL], pu32x4 (&ml)[NC], int code) {
+__device__ __forceinline__ void rgather_chunks(PCtx& c, __amdgpu_buffer_rsrc_t rs, int off, int stride, int coff, int mloff, int mloff2, int mlcoff,
+                                               pu32x4 (&v)[NC][NL], pu32x4 (&ml)[NC], pu32x4 (&ml2)[NC], int code) {
     unsigned spins = 0;
     while (true) {
         v[0][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
@@ -210,6 +216,7 @@ __device__ __forceinline__ void rgather_chunks(PCtx& c, __amdgpu_buffer_rsrc_t r
         for (int i = 0; i < NL; ++i)
             if (cc + i > 0) v[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + cc * coff, i * stride, 16);
         ml[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff + cc * mlcoff, 0, 16);
+        ml2[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff2 + cc * mlcoff, 0, 16);
     }
     while (true) {
         bool again = false;
@@ -219,6 +226,7 @@ __device__ __forceinline__ void rgather_chunks(PCtx& c, __amdgpu_buffer_rsrc_t r
             for (int i = 0; i < NL; ++i)
                 if (cc + i > 0 && __any(!rclean(v[cc][i]))) { v[cc][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + cc * coff, i * stride, 16); again = true; }
             if (__any(!rclean(ml[cc]))) { ml[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff + cc * mlcoff, 0, 16); again = true; }
+            if (__any(!rclean(ml2[cc]))) { ml2[cc] = __builtin_amdgcn_raw_buffer_load_b128(rs, mloff2 + cc * mlcoff, 0, 16); again = true; }
         }
         if (!again) break;
         if (spin_fail(c, spins, code, 1)) break;
@@ -273,9 +281,12 @@ __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ri
             for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-            if (WB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            lds_st(c.ctl + kCtlFilled, fseq);
+            if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
+            else {
+                if (WB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                lds_st(c.ctl + kCtlFilled, fseq);
+            }
             ++fseq;
         }
     }
@@ -284,7 +295,7 @@ __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ri
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------
-template <int R, int WB, int KVB>       // padded row count (8 or 16); bf16 weight storage; bf16 KV cache
+template <int R, int WB, int KVB, int HDR = 256>       // padded row count (8 or 16); bf16 weight storage; bf16 KV cache; real head_dim (256 / 128 / 64)
 __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     constexpr int D = kRD, HD = kRHD;
     constexpr int G = R / 4, KK = 16 / G;            // row groups, k positions (quads) per MFMA step
@@ -299,8 +310,8 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     float* resid = stat + 2 * kPCW * 16;             // [R] float4: the residual of this workgroup's four output columns
     float* resid2 = resid + kRMaxRows * 4;           // [2][R] float4: x' of the eight columns this workgroup finishes in phase E
     float* gbs = resid2 + 2 * kRMaxRows * 4;              // [kPCW][32 gain quads | 32 bias quads] of the LayerNorm a phase applies
-    float* ascr = gbs + kPCW * 64 * 4;               // attention: q[256] | m_s[8] | l_s[8] | o_s[8][256]
-    unsigned* ctl = reinterpret_cast<unsigned*>(ascr + 256 + 16 + kPCW * 256);
+    float* ascr = gbs + kPCW * 64 * 4;               // attention: q[256] | m_s[8][4] | l_s[8][4] | o_s[8][256]
+    unsigned* ctl = reinterpret_cast<unsigned*>(ascr + 256 + 64 + kPCW * 256);
     if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = 0u;
     __syncthreads();
 
@@ -315,7 +326,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     const int wave = c.wave, wg = c.wg;
 #define GVC_PHASE_BEGIN() asm volatile("" : "+v"(c.lane), "+s"(Lp))
     const unsigned rmask = A.ring_slots - 1;
-    const int H = A.n_head;
+    constexpr int hd = HDR;                          // real head_dim: 256, 128 or 64
+    constexpr int H = D / hd;
+    constexpr int lpk = hd >> 2;                     // lanes of a wave that share a real head (64, 32 or 16)
+    constexpr int SH = D / HD;                       // super-heads (256 dims each): what phase B's workgroups are numbered by
     // key chunks per (row, head): from the longest context among the rows (per-slot lengths live on the device: every workgroup
     // reads the same few words and decides alike)
     int nch;
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
         if (nch > A.nchunks) nch = A.nchunks;
     }
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(A.bufs, (unsigned)rows_buf_bytes());
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = 1.0f / sqrtf((float)hd);
     // stamps (GVC_PERSIST_STAMPS): workgroup 0, every layer: [(l * 5 + p) * 4 + k], k = 0 input gathered, 1 output published, 2 extra;
     // every workgroup at layer 2: [20 (L + 2) + (wg * 5 + p) * 4 + k]
     const bool stamp0 = A.dbg && wave == 0 && c.lane == 0;
@@ -490,12 +504,12 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 const int eo = (kRoffQKV + rn * 3 * D + col) * 4;
                 rpublish(brs, pc + eo, po + eo, s);
                 if (col >= D && rn < A.rows) {                // append k / v of this row to its stream's cache (read by later launches)
-                    const int which = col / D, ci = col - which * D, h = ci / HD, j = ci - h * HD;
+                    const int which = col / D, ci = col - which * D, h = ci / hd, j = ci - h * hd;
                     const int bstream = rn / A.T, t = rn - bstream * A.T, slot = A.slots[bstream];
                     const int pos = (A.base_len ? A.base_len[slot] : 0) + t;
                     if (pos < A.max_seq) {
                         float* cache = which == 1 ? Lp->kcache : Lp->vcache;
-                        const size_t e = (((size_t)slot * H + h) * A.max_seq + pos) * HD + j;
+                        const size_t e = (((size_t)slot * H + h) * A.max_seq + pos) * hd + j;
                         if (KVB) {
                             uint2 hv;
                             hv.x = (__float_as_uint(s.x) >> 16) | (__float_as_uint(s.y) & 0xffff0000u);
@@ -508,9 +522,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             stamp_at(l, 0, 1);
         }
         // =================== B: attention of one (row, head, key chunk) per workgroup ===================
-        if (wg < R * H * nch) {
+        if (wg < R * SH * nch) {
             GVC_PHASE_BEGIN();
-            const int ch = wg % nch, h = (wg / nch) % H, n = wg / (nch * H);
+            const int ch = wg % nch, h = (wg / nch) % SH, n = wg / (nch * SH);           // h: super-head
+            const int sub = lane / lpk, hreal = h * (HD / hd) + sub, dl = (lane - sub * lpk) * 4;    // this lane's real head, its dims inside it
             const bool active = n < A.rows;
             const int bstream = active ? n / A.T : 0, t = active ? n - bstream * A.T : 0, r0 = bstream * A.T;
             const int slot = A.slots[bstream];
@@ -518,36 +533,37 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int k0 = active ? (int)(((long long)base * ch) / nch) : 0, k1 = active ? (int)(((long long)base * (ch + 1)) / nch) : 0;
             const bool last = active && ch == nch - 1;           // the new rows [r0, n] of this very step belong to the last chunk
             constexpr int ESZ = KVB ? 2 : 4;                     // bytes per cache element
-            const unsigned head_bytes = (unsigned)A.max_seq * HD * ESZ;
-            const size_t head_off = ((size_t)slot * H + h) * A.max_seq * HD * ESZ;
-            const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Lp->kcache) + head_off, head_bytes);
-            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Lp->vcache) + head_off, head_bytes);
+            // the slot's rows of the layer's K / V cache as buffers ([head][max_seq][hd]); a lane addresses its own real head
+            const unsigned slot_bytes = (unsigned)H * A.max_seq * hd * ESZ;
+            const size_t slot_off = (size_t)slot * H * A.max_seq * hd * ESZ;
+            const __amdgpu_buffer_rsrc_t krs = make_rsrc(reinterpret_cast<const char*>(Lp->kcache) + slot_off, slot_bytes);
+            const __amdgpu_buffer_rsrc_t vrs = make_rsrc(reinterpret_cast<const char*>(Lp->vcache) + slot_off, slot_bytes);
             constexpr int U = 10;                                // keys per wave and pass: 80 keys of the chunk per pass
             float4 kr[U], vr[U];
             auto load_pass = [&](int kb) {                       // keys kb + wave + 8 u of the cache (written by earlier launches)
-                const int voff = ((kb + wave) * HD + lane * 4) * ESZ;
+                const int voff = ((hreal * A.max_seq + kb + wave) * hd + dl) * ESZ;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (KVB) {                                   // 8 bytes = 4 bf16 per lane, widened at use
                         pu32x2 kq = {0u, 0u}, vq = {0u, 0u};
                         if (kb + wave + u * kPCW < k1) {
-                            kq = __builtin_amdgcn_raw_buffer_load_b64(krs, voff, u * kPCW * HD * ESZ, 0);
-                            vq = __builtin_amdgcn_raw_buffer_load_b64(vrs, voff, u * kPCW * HD * ESZ, 0);
+                            kq = __builtin_amdgcn_raw_buffer_load_b64(krs, voff, u * kPCW * hd * ESZ, 0);
+                            vq = __builtin_amdgcn_raw_buffer_load_b64(vrs, voff, u * kPCW * hd * ESZ, 0);
                         }
                         kr[u] = make_float4(__uint_as_float(kq.x << 16), __uint_as_float(kq.x & 0xffff0000u), __uint_as_float(kq.y << 16), __uint_as_float(kq.y & 0xffff0000u));
                         vr[u] = make_float4(__uint_as_float(vq.x << 16), __uint_as_float(vq.x & 0xffff0000u), __uint_as_float(vq.y << 16), __uint_as_float(vq.y & 0xffff0000u));
                     } else {
                         pu32x4 kq = {0u, 0u, 0u, 0u}, vq = {0u, 0u, 0u, 0u};
                         if (kb + wave + u * kPCW < k1) {
-                            kq = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * HD * ESZ, 0);
-                            vq = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * HD * ESZ, 0);
+                            kq = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, u * kPCW * hd * ESZ, 0);
+                            vq = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, u * kPCW * hd * ESZ, 0);
                         }
                         kr[u] = as_f4(kq); vr[u] = as_f4(vq);
                     }
                 }
             };
             load_pass(k0);                                       // requested ahead of the seam
-            // q of (row, head): 256 floats, one 16-byte load per lane of wave 0
+            // q of (row, super-head): 256 floats, one 16-byte load per lane of wave 0
             if (wave == 0 && active) {
                 pu32x4 qv[1];
                 rgather<1>(c, brs, pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16, 0, qv, 200 + l);
@@ -598,33 +614,33 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) sc[u] = dot4(q4, kr[u]);
 #pragma unroll
-                for (int u = 0; u < U; ++u) sc[u] = kb + wave + u * kPCW < k1 ? wave_sum(sc[u]) * scale : -INFINITY;
+                for (int u = 0; u < U; ++u) sc[u] = kb + wave + u * kPCW < k1 ? group_sum(sc[u], lpk) * scale : -INFINITY;
                 fold(sc, vr, std::integral_constant<int, U>());
             }
             {
                 float sc[2];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) sc[jj] = has_new[jj] ? wave_sum(dot4(q4, kn[jj])) * scale : -INFINITY;
+                for (int jj = 0; jj < 2; ++jj) sc[jj] = has_new[jj] ? group_sum(dot4(q4, kn[jj]), lpk) * scale : -INFINITY;
                 fold(sc, vn, std::integral_constant<int, 2>());
             }
-            float* m_s = ascr + 256;
-            float* l_s = m_s + kPCW;
-            float* o_s = l_s + kPCW;
-            if (lane == 0) { m_s[wave] = m; l_s[wave] = lsum; }
+            float* m_s = ascr + 256;                             // [kPCW][4 real heads of the super-head]
+            float* l_s = m_s + kPCW * 4;
+            float* o_s = l_s + kPCW * 4;
+            if (dl == 0) { m_s[wave * 4 + sub] = m; l_s[wave * 4 + sub] = lsum; }
             *reinterpret_cast<float4*>(o_s + wave * 256 + lane * 4) = o;
             cbar(c);
             if (wave == 0) {
                 float M = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < kPCW; ++i) M = fmaxf(M, m_s[i]);
+                for (int i = 0; i < kPCW; ++i) M = fmaxf(M, m_s[i * 4 + sub]);
                 float Lt = 0.f;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (M > -INFINITY) {
+                if (M > -INFINITY) {                                       // (uniform: every real head sees the same keys)
 #pragma unroll
                     for (int i = 0; i < kPCW; ++i) {
-                        const float wgt = __expf(m_s[i] - M);              // waves without a key: exp(-inf) = 0
+                        const float wgt = __expf(m_s[i * 4 + sub] - M);    // waves without a key: exp(-inf) = 0
                         const float4 oi = *reinterpret_cast<const float4*>(o_s + i * 256 + lane * 4);
-                        Lt += wgt * l_s[i];
+                        Lt += wgt * l_s[i * 4 + sub];
                         acc.x = fmaf(wgt, oi.x, acc.x); acc.y = fmaf(wgt, oi.y, acc.y);
                         acc.z = fmaf(wgt, oi.z, acc.z); acc.w = fmaf(wgt, oi.w, acc.w);
                     }
@@ -637,8 +653,8 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 const int fl = (q / KK) * 64 + (((n >> 2) * KK + (q % KK)) * 4 + (n & 3));
                 const int eo = (kRoffOP + ch * R * D) * 4 + fl * 16;
                 rpublish(brs, pc + eo, po + eo, acc);
-                if (lane == 0) {
-                    const int mo = (kRoffML + ((ch * kRMaxRows + n) * 4 + h) * 4) * 4;
+                if (dl == 0) {                                             // one {m, l} piece per real head
+                    const int mo = (kRoffML + ((ch * kRMaxRows + n) * kRMaxHeads + hreal) * 4) * 4;
                     rpublish(brs, pc + mo, po + mo, make_float4(M, Lt, 0.f, 0.f));
                 }
             }
@@ -657,46 +673,62 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
             } else {
-                // several chunks: merge their (o, m, l) in chunk order; the wave's 32 k-quads lie in head wave / 2.  All chunks are
-                // requested in one round trip (16 rows x 4 chunks: two trips of two chunks, 64 registers each)
-                const int hh = wave >> 1;
+                // several chunks: merge their (o, m, l) in chunk order.  The wave's 32 k-quads (128 dims) lie in ONE real head with
+                // head_dim 256 / 128 and in TWO with head_dim 64 (the first and the second half of its steps): two {m, l} sets, `a` for
+                // steps < NSX / 2 and `b` for the rest (the same head twice unless head_dim is 64).  All chunks are requested in one
+                // round trip (16 rows x 4 chunks: two trips of two chunks, 64 registers each)
+                const int ha = (wave * 128) / hd, hb = (wave * 128 + 64) / hd;
                 const int ooff = pc + kRoffOP * 4 + s0 * 1024 + lane * 16, ocoff = R * D * 4;
-                const int moff = pc + (kRoffML + (n * 4 + hh) * 4) * 4, mcoff = kRMaxRows * 4 * 4 * 4;
-                float M = 0.f, Wt = 0.f;                     // running max, sum of weights (at max M)
-                auto merge = [&](const pu32x4 (&raw)[NSX], pu32x4 mlv, bool first) {
-                    const float mc = __uint_as_float(mlv.x), lc = __uint_as_float(mlv.y);
+                const int moff = pc + (kRoffML + (n * kRMaxHeads + ha) * 4) * 4, moff2 = pc + (kRoffML + (n * kRMaxHeads + hb) * 4) * 4;
+                const int mcoff = kRMaxRows * kRMaxHeads * 4 * 4;
+                float Ma = 0.f, Wa = 0.f, Mb = 0.f, Wb = 0.f;            // running max, sum of weights (at that max), per half
+                auto merge = [&](const pu32x4 (&raw)[NSX], pu32x4 mla, pu32x4 mlb, bool first) {
                     if (first) {
 #pragma unroll
                         for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
-                        M = mc; Wt = lc;
+                        Ma = __uint_as_float(mla.x); Wa = __uint_as_float(mla.y);
+                        Mb = __uint_as_float(mlb.x); Wb = __uint_as_float(mlb.y);
                         return;
                     }
-                    const float Mn = fmaxf(M, mc);
-                    const float wa = Wt * __expf(M - Mn), wb = lc * __expf(mc - Mn);
-                    const float tot = wa + wb;
-                    const float fa = tot > 0.f ? wa / tot : 0.f, fb = tot > 0.f ? wb / tot : 0.f;
+                    float fa[2], fb[2];
+                    {
+                        const float mc = __uint_as_float(mla.x), lc = __uint_as_float(mla.y);
+                        const float Mn = fmaxf(Ma, mc);
+                        const float wa = Wa * __expf(Ma - Mn), wb = lc * __expf(mc - Mn);
+                        const float tot = wa + wb;
+                        fa[0] = tot > 0.f ? wa / tot : 0.f; fb[0] = tot > 0.f ? wb / tot : 0.f;
+                        Ma = Mn; Wa = tot;
+                    }
+                    {
+                        const float mc = __uint_as_float(mlb.x), lc = __uint_as_float(mlb.y);
+                        const float Mn = fmaxf(Mb, mc);
+                        const float wa = Wb * __expf(Mb - Mn), wb = lc * __expf(mc - Mn);
+                        const float tot = wa + wb;
+                        fa[1] = tot > 0.f ? wa / tot : 0.f; fb[1] = tot > 0.f ? wb / tot : 0.f;
+                        Mb = Mn; Wb = tot;
+                    }
 #pragma unroll
                     for (int i = 0; i < NSX; ++i) {
                         const float4 oc = as_f4(raw[i]);
-                        ov[i].x = fa * ov[i].x + fb * oc.x; ov[i].y = fa * ov[i].y + fb * oc.y;
-                        ov[i].z = fa * ov[i].z + fb * oc.z; ov[i].w = fa * ov[i].w + fb * oc.w;
+                        const float a = fa[i < NSX / 2 ? 0 : 1], b = fb[i < NSX / 2 ? 0 : 1];
+                        ov[i].x = a * ov[i].x + b * oc.x; ov[i].y = a * ov[i].y + b * oc.y;
+                        ov[i].z = a * ov[i].z + b * oc.z; ov[i].w = a * ov[i].w + b * oc.w;
                     }
-                    M = Mn; Wt = tot;
                 };
                 if (nch == 2) {
-                    pu32x4 raw[2][NSX], ml[2];
-                    rgather_chunks<2, NSX>(c, brs, ooff, 1024, ocoff, moff, mcoff, raw, ml, 320 + l);
-                    merge(raw[0], ml[0], true); merge(raw[1], ml[1], false);
+                    pu32x4 raw[2][NSX], ml[2], ml2[2];
+                    rgather_chunks<2, NSX>(c, brs, ooff, 1024, ocoff, moff, moff2, mcoff, raw, ml, ml2, 320 + l);
+                    merge(raw[0], ml[0], ml2[0], true); merge(raw[1], ml[1], ml2[1], false);
                 } else if constexpr (NSX <= 4) {
-                    pu32x4 raw[4][NSX], ml[4];
-                    rgather_chunks<4, NSX>(c, brs, ooff, 1024, ocoff, moff, mcoff, raw, ml, 320 + l);
-                    merge(raw[0], ml[0], true); merge(raw[1], ml[1], false); merge(raw[2], ml[2], false); merge(raw[3], ml[3], false);
+                    pu32x4 raw[4][NSX], ml[4], ml2[4];
+                    rgather_chunks<4, NSX>(c, brs, ooff, 1024, ocoff, moff, moff2, mcoff, raw, ml, ml2, 320 + l);
+                    merge(raw[0], ml[0], ml2[0], true); merge(raw[1], ml[1], ml2[1], false); merge(raw[2], ml[2], ml2[2], false); merge(raw[3], ml[3], ml2[3], false);
                 } else {
 #pragma unroll 1
                     for (int c2 = 0; c2 < 4; c2 += 2) {
-                        pu32x4 raw[2][NSX], ml[2];
-                        rgather_chunks<2, NSX>(c, brs, ooff + c2 * ocoff, 1024, ocoff, moff + c2 * mcoff, mcoff, raw, ml, 320 + l);
-                        merge(raw[0], ml[0], c2 == 0); merge(raw[1], ml[1], false);
+                        pu32x4 raw[2][NSX], ml[2], ml2[2];
+                        rgather_chunks<2, NSX>(c, brs, ooff + c2 * ocoff, 1024, ocoff, moff + c2 * mcoff, moff2 + c2 * mcoff, mcoff, raw, ml, ml2, 320 + l);
+                        merge(raw[0], ml[0], ml2[0], c2 == 0); merge(raw[1], ml[1], ml2[1], false);
                     }
                 }
             }

@@ -289,6 +289,96 @@ class GPT(nn.Module):
         self.last_latents = None          # (per-group latents are not kept: the callers of this path want tokens)
         return out
 
+    @torch.inference_mode()
+    def generate_rolling(self, jobs, **generate_kwargs):
+        """generate_groups with a ROLLING set of streams (greedy decoding only): jobs = [(cond_latents [B_i, 32, d], text_inputs
+        [B_i, Tc_i]), ...] are admitted in order as KV slots become free, and a job leaves the decode when its budget is spent or all
+        its rows have emitted the stop token -- the slots it frees go to the next job at once, so the decode step keeps as many rows as
+        the context has slots instead of draining to the longest class (configs[2]: the 47-step tail of a micro-batch's 6 s class runs
+        beside the NEXT micro-batch's 4 s class).  Streams are independent given their prefix, so every job gets what generate()
+        returns for it (reference gpt.py:594-609 + stream_generator.py:861-874 per row).  `max_new_tokens`: one budget, or a list
+        with one per job.  Returns a list of int64 [B_i, n_i] in job order."""
+        self._need_engine()
+        kw = dict(generate_kwargs)
+        group = kw.pop("group", 16)
+        kw.pop("class_seeds", None)
+        max_rows = kw.pop("max_rows", None)      # streams in flight at most (default: every KV slot of the context)
+        if not (kw.get("top_k", 0) == 1 or not kw.get("do_sample", True)) or kw.get("num_beams", 1) != 1:
+            raise NotImplementedError("generate_rolling serves greedy decoding (top_k = 1): with sampling use generate_groups")
+        budgets = kw.get("max_new_tokens")
+        if isinstance(budgets, (list, tuple)):
+            if len(budgets) != len(jobs):
+                raise ValueError(f"generate_rolling: {len(budgets)} token budgets for {len(jobs)} jobs")
+            budgets = [int(b) for b in budgets]
+        else:
+            budgets = [int(budgets or self.max_gen_mel_tokens)] * len(jobs)
+        if not jobs:
+            return []
+        dev = jobs[0][1].device
+        eng = self.engine
+        n0s = [int(t.shape[1]) + int(c.shape[1]) + 3 for c, t in jobs]            # prefix rows (cond + text + 2) + the start token
+        width = max(n0 + b for n0, b in zip(n0s, budgets)) + 8
+        S = min(self.max_slots, int(max_rows)) if max_rows else self.max_slots
+        if max(int(t.shape[0]) for _, t in jobs) > S:
+            raise ValueError(f"generate_rolling: a job has more rows than streams may be in flight ({S}; KV slots {self.max_slots})")
+        ids_all = torch.ones(S, width, device=dev, dtype=torch.int32)
+        len_all = torch.zeros(S, device=dev, dtype=torch.int32)
+        fin_all = torch.zeros(S, device=dev, dtype=torch.int32)
+        samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
+                    top_p=kw.get("top_p", 1.0), top_k=1)
+        params = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
+        stats = getattr(self, "groups_stats", None)
+        free = list(range(S))
+        live, out, nxt = [], [None] * len(jobs), 0
+        while nxt < len(jobs) or live:
+            # admit jobs in order while their rows fit
+            while nxt < len(jobs) and int(jobs[nxt][1].shape[0]) <= len(free):
+                c, t = jobs[nxt]
+                b = int(t.shape[0])
+                sl = torch.tensor(free[:b], device=dev, dtype=torch.int32)
+                del free[:b]
+                prefix = eng.prefix_embeddings(c.to(torch.float32).contiguous(), t.to(torch.int32).contiguous())
+                eng.prefill(sl, prefix, want_outputs=False)
+                idx = sl.long()
+                ids_all[idx] = 1
+                ids_all[idx, n0s[nxt] - 1] = self.start_audio_token
+                len_all[idx] = n0s[nxt]
+                fin_all[idx] = 0
+                live.append(dict(job=nxt, slots=sl, rows=b, n0=n0s[nxt], budget=budgets[nxt], done=0, toks=[]))
+                nxt += 1
+            n = min(group, min(j["budget"] - j["done"] for j in live))
+            rows = torch.cat([j["slots"] for j in live])
+            idx = rows.long()
+            W = max(j["n0"] + j["done"] for j in live) + n + 8
+            ids = ids_all[idx, :W].contiguous()
+            ids_len = len_all[idx].contiguous()
+            fin = fin_all[idx].contiguous()
+            toks = torch.full((int(rows.shape[0]), n), self.stop_audio_token, device=dev, dtype=torch.int32)
+            eng.generate(rows, ids, ids_len, fin, params, 0, n, toks, None, max_keys=W - 8)
+            ids_all[idx, :W] = ids
+            len_all[idx] = ids_len
+            fin_all[idx] = fin
+            fin_h = fin.cpu()                                      # (synchronises)
+            eng.health()
+            if stats is not None:
+                stats["joint"] += 1
+            r = 0
+            keep = []
+            for j in live:
+                j["toks"].append(toks[r:r + j["rows"]])
+                j["done"] += n
+                if j["done"] >= j["budget"] or bool(fin_h[r:r + j["rows"]].all()):
+                    t = torch.cat(j["toks"], 1).long()
+                    out[j["job"]] = t[:, :self._stop_len(t)]
+                    free.extend(int(v) for v in j["slots"].tolist())
+                    free.sort()
+                else:
+                    keep.append(j)
+                r += j["rows"]
+            live = keep
+        self.last_latents = None
+        return out
+
     def _stop_len(self, toks):
         """steps the reference loop runs: up to and including the step where the last row emits the stop token"""
         is_stop = toks == self.stop_audio_token

@@ -110,10 +110,62 @@ def convert_batch(model, src_wavs, cond_latent, seg_len=6.0, max_len=None, n_seg
     return out
 
 
+def _wave_classes(m, src_wavs, seg, min_len, n_seg):
+    """the (segment index, segment length) classes of a wave of utterances, content codes computed: [(s, rows, codes, n_samples)]"""
+    per_utt = [list(segments(w.to(m.device), seg, min_len)) for w in src_wavs]
+    classes = []
+    for s in range(n_seg):
+        groups = {}
+        for b, p in enumerate(per_utt):
+            if s < len(p):
+                groups.setdefault(p[s].shape[-1], []).append(b)
+        for n_samples, rows in sorted(groups.items(), reverse=True):
+            wav = torch.cat([per_utt[b][s] for b in rows], 0)
+            feat = m.content_extractor.extract_content_features(wav)
+            codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+            classes.append((s, rows, codes, n_samples))
+    return classes
+
+
+@torch.inference_mode()
+def convert_rolling(model, src_wavs, cond_latent, seg_len=6.0, micro_batch=8, max_len=None, n_seg=None, tokens_per_second=None, **gen_kwargs):
+    """convert_batch over ALL of a rank's utterances with a rolling decode (layers/gpt.py generate_rolling; greedy decoding): the
+    utterances are taken in waves of `micro_batch` -- a wave shares its ContentVec / DVAE / prefill calls per (segment, length) class
+    exactly as in convert_batch -- but a class joins the decode as soon as KV slots are free and leaves it when its budget is spent or
+    its rows have stopped, so the step keeps 2 x micro_batch rows busy across wave boundaries instead of draining to the longest class
+    of every wave.  Same tokens as convert_batch (streams are independent given their prefix).  Returns int32 [n, n_seg, max_len]."""
+    m = model
+    stop = m.gpt.stop_audio_token
+    max_len = max_len or m.gpt.max_gen_mel_tokens
+    seg = int(seg_len * m.content_sample_rate)
+    min_len = int(0.32 * m.content_sample_rate)
+    n_seg = n_seg or max(_n_segments(int(w.shape[-1]), seg) for w in src_wavs)
+    out = torch.full((len(src_wavs), n_seg, max_len), stop, dtype=torch.int32, device=m.device)
+    kw = dict(_sampling_kwargs(m))
+    kw.update(gen_kwargs)
+    cap = kw.get("max_new_tokens") or max_len
+    jobs, where, budgets = [], [], []
+    for i in range(0, len(src_wavs), micro_batch):
+        for s, rows, codes, ns in _wave_classes(m, src_wavs[i:i + micro_batch], seg, min_len, n_seg):
+            jobs.append((cond_latent.expand(len(rows), -1, -1).contiguous(), codes))
+            where.append((s, [i + r for r in rows]))
+            budgets.append(max(1, min(cap, int(round(ns / m.content_sample_rate * tokens_per_second)))) if tokens_per_second else cap)
+    kw["max_new_tokens"] = budgets
+    # streams in flight: what one wave holds (its classes decoded jointly, as in convert_batch) -- the rolling decode never runs a
+    # larger step than the fixed micro-batch does, it only keeps that step full
+    kw.setdefault("max_rows", max(max(len(r) for _, r in where), min(n_seg * micro_batch, getattr(m.gpt, "max_slots", 8))))
+    gens = m.gpt.generate_rolling(jobs, **kw)
+    for (s, rows), gen in zip(where, gens):
+        out[rows, s, :gen.shape[1]] = gen.to(torch.int32)
+    return out
+
+
 @torch.inference_mode()
 def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank=0, world=1, process_group=None, **gen_kwargs):
     """All utterances of the job (any lengths), sharded by rank (see plan), in waves of `micro_batch`; no collective while
     converting, ONE all_gather of the padded token ids at the end.  Returns int32 [n_utts, n_seg, max_len] on every rank.
+    rolling (gen_kwargs, default False): greedy runs only -- decode with a rolling set of streams (convert_rolling) instead of one joint
+    decode per wave: same tokens, no drain at the end of every wave.
     process_group: the torch.distributed group of the all_gather (default: the world).  Everything in gen_kwargs goes to
     GPT.generate_groups -- including its `group` (decode steps per host look at the finished flags), which this function's
     process-group parameter used to shadow: with `group=48` in the kwargs every N > 1 run died in the all_gather."""
@@ -125,6 +177,10 @@ def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank
     n_seg = max(_n_segments(n, seg) for n in lengths)
     max_len = m.gpt.max_gen_mel_tokens
     local = torch.full((len(mine), n_seg, max_len), m.gpt.stop_audio_token, dtype=torch.int32, device=m.device)
+    rolling = bool(gen_kwargs.pop("rolling", False)) and gen_kwargs.get("top_k", m.config.top_k) == 1 and hasattr(m.gpt, "generate_rolling")
+    if rolling and mine:
+        local[:] = convert_rolling(m, [src_wavs[j] for j in mine], cond, seg_len, micro_batch, max_len, n_seg, **gen_kwargs)
+        return gather_token_ids(local, len(src_wavs), m.gpt.stop_audio_token, rank, world, process_group, lengths)
     for i in range(0, len(mine), micro_batch):
         wave = mine[i:i + micro_batch]
         local[i:i + len(wave)] = convert_batch(m, [src_wavs[j] for j in wave], cond, seg_len, max_len, n_seg, utt_ids=wave, **gen_kwargs)

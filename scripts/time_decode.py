@@ -8,7 +8,7 @@ from genvc_amd.engine import GptEngine, sample_params
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 Tc = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-dims = gcfg.gpt_dims(gcfg.DEFAULT_MODEL_ARGS)
+dims = gcfg.gpt_dims(dict(gcfg.DEFAULT_MODEL_ARGS, gpt_n_heads=int(os.environ.get("HEADS", "4"))))
 w = synth.make_weights(1, synth.gpt_weight_spec(dims), device="cuda")
 eng = GptEngine(dims, max_slots=max(B, 8), max_rows=4096)
 eng.bind(w)

@@ -26,12 +26,13 @@ def _engine(margs, seed, max_slots, weight_dtype="fp32"):
     return dims, w, eng
 
 
-@pytest.mark.parametrize("B", [2, 5, 8, 11, 16])
-def test_rows_step_batched_decode_vs_oracle(B):
+@pytest.mark.parametrize("B,H", [(2, 4), (5, 4), (8, 4), (11, 4), (16, 4), (3, 16), (8, 16), (13, 16), (8, 8), (16, 8)])
+def test_rows_step_batched_decode_vs_oracle(B, H):
     """B streams with ragged cache lengths and scattered KV slots: teacher-forced logits / latents of every step against the
-    oracle (8 padded rows up to 8 streams, 16 beyond), and the K/V rows a step appends feed the later steps"""
+    oracle (8 padded rows up to 8 streams, 16 beyond), and the K/V rows a step appends feed the later steps.  H = 16 / 8: the
+    reference's config default of 16 heads (configs/genVC_configs.py:132; head_dim 64) and 8 heads of 128 on the same one-launch step"""
     from oracle import genvc_oracle as O
-    dims, w, eng = _engine(WIDE2, 3, 24)
+    dims, w, eng = _engine(dict(WIDE2, gpt_n_heads=H), 3, 24)
     wc = {k: v.cpu() for k, v in w.items()}
     dev = "cuda"
     slots = torch.randperm(24, generator=torch.Generator().manual_seed(B))[:B].to(dev).int().contiguous()
@@ -54,14 +55,16 @@ def test_rows_step_batched_decode_vs_oracle(B):
     eng.close()
 
 
-@pytest.mark.parametrize("B,Tc,n", [(6, 120, 24), (12, 150, 20), (5, 300, 16), (16, 300, 12)],
-                         ids=["8rows_2chunks", "16rows_2chunks", "8rows_4chunks", "16rows_4chunks"])
-def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n):
+@pytest.mark.parametrize("B,Tc,n,H", [(6, 120, 24, 4), (12, 150, 20, 4), (5, 300, 16, 4), (16, 300, 12, 4), (6, 120, 16, 16), (12, 300, 10, 16),
+                                      (7, 300, 10, 8)],
+                         ids=["8rows_2chunks", "16rows_2chunks", "8rows_4chunks", "16rows_4chunks", "8rows_2chunks_16heads", "16rows_4chunks_16heads",
+                              "8rows_4chunks_8heads"])
+def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n, H):
     """contexts past 128 / 288 cached positions: the keys of a (row, head) are split over 2 / 4 workgroups and phase C merges the
     chunk partials; greedy ids against the oracle wherever the oracle's own top-1 / top-2 margin is not at rounding level"""
     from test_gpu_gpt import run_generate
     from oracle import genvc_oracle as O
-    dims, w, eng = _engine(WIDE2, 31, max(B, 8))
+    dims, w, eng = _engine(dict(WIDE2, gpt_n_heads=H), 31, max(B, 8))
     wc = {k: v.cpu() for k, v in w.items()}
     cond = synth.uniform(31, "cond", (B, 32, 1024), 1.0)
     codes = synth.integers(31, "codes", (B, Tc), 256)
@@ -83,14 +86,14 @@ def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n):
     eng.close()
 
 
-@pytest.mark.parametrize("B,Tc,L", [(1, 13, 2), (1, 5, 2), (2, 5, 2), (1, 13, 30)],
-                         ids=["16rows_one_stream", "8rows_one_stream", "16rows_two_streams", "16rows_one_stream_30_layers"])
-def test_rows_step_cached_chunk_prefill_vs_full_prefill_and_oracle(B, Tc, L):
+@pytest.mark.parametrize("B,Tc,L,H", [(1, 13, 2, 4), (1, 5, 2, 4), (2, 5, 2, 4), (1, 13, 30, 4), (1, 13, 2, 16), (2, 5, 2, 8)],
+                         ids=["16rows_one_stream", "8rows_one_stream", "16rows_two_streams", "16rows_one_stream_30_layers", "16rows_16_heads", "16rows_two_streams_8_heads"])
+def test_rows_step_cached_chunk_prefill_vs_full_prefill_and_oracle(B, Tc, L, H):
     """the <= 16 uncached rows of a streaming chunk (conditioning rows still in the KV cache): causal attention over the cached
     prefix plus the new rows of the same stream, against the same prefill computed in full on fresh slots and against the oracle;
     the decode steps that follow read the K/V rows the one-launch step appended"""
     from oracle import genvc_oracle as O
-    dims, w, eng = _engine(dict(WIDE2, gpt_layers=L), 3, 8)
+    dims, w, eng = _engine(dict(WIDE2, gpt_layers=L, gpt_n_heads=H), 3, 8)
     wc = {k: v.cpu() for k, v in w.items()}
     dev = "cuda"
     cond = synth.uniform(91, "cond_latents", (B, 32, dims["d_model"]), 1.0)
@@ -277,6 +280,15 @@ def test_offline_micro_batch_classes_decode_together_and_match_both_reference_fi
     n6, n4 = g6["tokens"].shape[1], g4["tokens"].shape[1]
     assert np.array_equal(out[0][:, :n6].cpu().numpy(), np.tile(g6["tokens"], (8, 1))), "6 s class: ids differ from the reference"
     assert np.array_equal(out[1][:, :n4].cpu().numpy(), np.tile(g4["tokens"], (8, 1))), "4 s class: ids differ from the reference"
+    # the ROLLING decode of two micro-batches (bench.py's offline leg, round 4): classes 6 s / 4 s / 6 s / 4 s with their duration
+    # budgets through 16 KV slots -- the second wave's 6 s class joins when the first wave's 4 s class has left (step 94), its 4 s class
+    # when the first 6 s class has (step 141): every stream still reproduces the reference's ids for its class
+    jobs = [groups[0], groups[1], groups[0], groups[1]]
+    roll = gpt.generate_rolling(jobs, group=48, **dict(kw, max_new_tokens=[n6, n4, n6, n4]))
+    assert gpt.engine.decode_variant() == 5
+    for i, o in enumerate(roll):
+        ref = g6["tokens"] if i % 2 == 0 else g4["tokens"]
+        assert np.array_equal(o.cpu().numpy(), np.tile(ref, (8, 1))), f"rolling decode, job {i}: ids differ from the reference"
     gpt.engine.close()
 
 

@@ -408,14 +408,18 @@ def test_stream_sessions_recover_from_a_hand_off_timeout(monkeypatch):
     srcs = [synth.synth_audio(80 + i, "src", 32000) for i in range(2)]
     solo = [synthesize_utt_streaming(m, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True) for i in range(2)]
     ss = StreamSessions(m, max_sessions=4, group=8)
-    sids = [ss.open(r) for r in refs]
-    for i, sid in enumerate(sids):
-        for sg in segments(srcs[i], 16000, 5120):
-            ss.push(sid, sg)
+    sids = [ss.open(refs[0])]
+    for sg in segments(srcs[0], 16000, 5120):
+        ss.push(sids[0], sg)
     wavs, steps = {}, 0
-    while not ss.idle():
+    while steps < 2 or not ss.idle():
         if steps == 1:
-            monkeypatch.setenv("GVC_PERSIST_TEST_GRID", "255")          # the second decode call of the first segments fails
+            # the second stream joins: the first decode call over TWO streams captures the rows step's graph -- one workgroup short.
+            # Stream 0 has emitted one group of 8 tokens by then, stream 1 nothing.
+            sids.append(ss.open(refs[1]))
+            for sg in segments(srcs[1], 16000, 5120):
+                ss.push(sids[1], sg)
+            monkeypatch.setenv("GVC_PERSIST_TEST_GRID", "255")
         for sid, chunks in ss.step().items():
             wavs.setdefault(sid, []).extend(chunks)
         if steps == 1:
@@ -510,6 +514,15 @@ def test_generate_groups_equals_separate_generate_calls():
         joint_b = m.gpt.generate_groups(groups, **dict(kw, max_new_tokens=budgets))
         for (c, t), a, nb in zip(groups, joint_b, budgets):
             assert a.shape[1] <= nb and torch.equal(a, m.gpt.generate(c, t, **dict(kw, max_new_tokens=nb)))
+    # rolling decode (generate_rolling): more jobs than KV slots hold at once, ragged budgets -- jobs are admitted as slots free up and
+    # every job gets its own generate() result
+    jobs = [groups[0], groups[1], groups[1], groups[0], (groups[1][0][:5].contiguous(), groups[1][1][:5].contiguous())]      # (>= 5 rows: the rows path, alone and together)
+    jb = [20, 7, 13, 9, 16]
+    rolled = m.gpt.generate_rolling(jobs, group=5, **dict(kw, max_new_tokens=jb))
+    for (c, t), a, nb in zip(jobs, rolled, jb):
+        assert a.shape[1] <= nb and torch.equal(a, m.gpt.generate(c, t, **dict(kw, max_new_tokens=nb)))
+    with pytest.raises(NotImplementedError):
+        m.gpt.generate_rolling(jobs, **dict(kw, top_k=15))
     # sampling: the groups run one after another, each class with its own random stream (seed + 7919 * class index: with one shared
     # seed every class would draw the same per-row sequences), the rows of a class keeping the counter RNG's per-row numbering
     kw_s = dict(kw, top_k=15, seed=7)

@@ -229,6 +229,7 @@ class _StubModel:
         max_slots = 16                                                        # KV slots: bounds the streams of one joint decode
         calls = []
         seen_kwargs = []
+        rolling_calls = []
         group_calls = []                                                      # streams per class of every generate_groups call
 
         def generate(self, cond, codes, **kw):
@@ -236,6 +237,10 @@ class _StubModel:
             n = 5 + codes.shape[1] % 6
             base = (codes.sum(1, keepdim=True) + (cond[0].sum() * 1000).long()) % 1000
             return (base + torch.arange(n)[None, :]) % 1024
+
+        def generate_rolling(self, jobs, **kw):                              # the real one keeps a rolling set of streams decoding
+            self.rolling_calls.append(([int(t.shape[0]) for _, t in jobs], kw.get("max_rows"), kw.get("max_new_tokens")))
+            return [self.generate(c, t) for c, t in jobs]
 
         def generate_groups(self, groups, **kw):                             # the real one decodes the groups together
             self.seen_kwargs.append(dict(kw))
@@ -250,6 +255,7 @@ class _StubModel:
         self.gpt.calls = []
         self.gpt.group_calls = []
         self.gpt.seen_kwargs = []
+        self.gpt.rolling_calls = []
 
     def get_gpt_cond_latents(self, audio, sr):
         return audio[:, :64].reshape(1, 32, 2)
@@ -356,3 +362,25 @@ def test_bench_self_launches_n_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.self_launch(argparse.Namespace(gpus=4))
     assert "only 1 GPU" in str(e.value)
+
+
+def test_convert_offline_rolling_matches_waves():
+    """the rolling offline driver (one generate_rolling call over all of a rank's classes, waves only share their front-end calls)
+    returns what the wave-by-wave driver returns; the streams in flight are capped at what one wave holds"""
+    from genvc_amd.parallel_offline import convert_offline
+    srcs, ref = _offline_job()
+    a, b = _StubModel(), _StubModel()
+    waves = convert_offline(a, srcs, ref, seg_len=6.0, micro_batch=2)
+    roll = convert_offline(b, srcs, ref, seg_len=6.0, micro_batch=2, rolling=True, tokens_per_second=2.0, max_new_tokens=12)
+    assert torch.equal(waves, roll)
+    assert len(b.gpt.rolling_calls) == 1 and not b.gpt.group_calls
+    rows, max_rows, budgets = b.gpt.rolling_calls[0]
+    assert sum(rows) == sum(-(-n // 96000) for n in [160000, 96000, 230000, 160000, 40000, 96000, 160000])     # one row per segment
+    assert max_rows == 3 * 2                                   # 3 segments per utterance at most x micro-batch of 2
+    assert len(budgets) == len(rows) and max(budgets) == 12 and min(budgets) >= 1
+    # sampling runs keep the wave-by-wave driver (per-class random streams)
+    c = _StubModel()
+    c.config.top_k = 15
+    convert_offline(c, srcs, ref, seg_len=6.0, micro_batch=2, rolling=True)
+    assert not c.gpt.rolling_calls and c.gpt.group_calls
+    _StubModel.config.top_k = 1
