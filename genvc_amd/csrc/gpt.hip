@@ -762,8 +762,11 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.dbg = c->p_dbg;
     static const int poll_b = getenv("GVC_PERSIST_POLL_B") ? atoi(getenv("GVC_PERSIST_POLL_B")) : 3;
     static const int poll_h = getenv("GVC_PERSIST_POLL_H") ? atoi(getenv("GVC_PERSIST_POLL_H")) : 3;
-    static const int loader_depth = getenv("GVC_PERSIST_LOADER_DEPTH") ? atoi(getenv("GVC_PERSIST_LOADER_DEPTH")) : 2;
-    A.poll_b = poll_b; A.poll_h = poll_h; A.loader_depth = loader_depth;
+    // fills in flight per loader wave: ONE is enough to keep up (11 KB/us per CU) and leaves the memory queue to the consumers' polls
+    // (round 4, with the XCD-local hand-off: 528-530 us per step against 530-533 with two, 547 against 554 at 110-174 keys; three: 554)
+    static const int loader_depth = getenv("GVC_PERSIST_LOADER_DEPTH") ? atoi(getenv("GVC_PERSIST_LOADER_DEPTH")) : 1;
+    static const int ln_one_pass = getenv("GVC_PERSIST_LN_ONE_PASS") ? atoi(getenv("GVC_PERSIST_LN_ONE_PASS")) : 0;
+    A.poll_b = poll_b; A.poll_h = poll_h; A.loader_depth = loader_depth; A.ln_one_pass = ln_one_pass;
     if (c->bf16) A.head_w = reinterpret_cast<const float*>(c->head_h);
     void* kargs[] = {&A};
     GVC_CHECK_HIP(hipLaunchKernel((const void*)persist_kernel(c), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->p_lds, s));

@@ -75,7 +75,8 @@ struct PersistArgs {
     int ring_slots;                 // power of two
     int hvec_floats, ascr_floats;
     unsigned long long* dbg;        // nullable: wall-clock stamps
-    int loader_depth;               // LDS-DMA fills in flight per loader wave (1..3; default 2)
+    int loader_depth;               // LDS-DMA fills in flight per loader wave (1..3; default 1)
+    int ln_one_pass;                // experiment: LayerNorm statistics in one pass (GVC_PERSIST_LN_ONE_PASS=1; default 0 = the reference's two-pass form)
     int poll_b, poll_h;             // back-off (s_sleep argument class 0 / 1 / 3) between polls of the q|k|v gather and of the XCD-local h gather
 };
 
@@ -249,19 +250,33 @@ __device__ __forceinline__ float row_partial(const char* ring, unsigned rmask, u
 }
 
 template <int ND>
-__device__ __forceinline__ void layer_norm_regs(float4 (&v)[ND], const float4 (&g)[ND], const float4 (&b)[ND]) {
+__device__ __forceinline__ void layer_norm_regs(float4 (&v)[ND], const float4 (&g)[ND], const float4 (&b)[ND], bool one_pass = false) {
     const float inv_d = 1.0f / (float)(256 * ND);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < ND; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    const float mean = wave_sum(s) * inv_d;
-    float q = 0.f;
+    float mean, rstd;
+    if (one_pass) {
+        // experiment: sum and sum of squares reduced side by side -- the two lane trees overlap instead of
+        // running one after the other; var = E[x^2] - mean^2 (another rounding than the reference's two-pass form)
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < ND; ++i) {
-        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        for (int i = 0; i < ND; ++i) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        const float ts = wave_sum(s), tq = wave_sum(q);
+        mean = ts * inv_d;
+        rstd = 1.0f / sqrtf(fmaxf(tq * inv_d - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean; }
+    } else {
+        mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
@@ -545,7 +560,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 float val = 0.f;
                 if (nmy > 0) {
                     vec_from_lds<ND>(xvec, lane, xv);
-                    layer_norm_regs<ND>(xv, g, b);
+                    layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
                     stamp_at(l, 0, 2);
                     wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
@@ -883,7 +898,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 float val = 0.f;
                 if (nmy > 0) {
                     vec_from_lds<ND>(xvec, lane, xv);
-                    layer_norm_regs<ND>(xv, g, b);
+                    layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
                     wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
 #pragma unroll
@@ -973,8 +988,8 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             cbar(c);
             stamp_at(L, 0, 0);
             vec_from_lds<ND>(xvec, lane, xv);
-            layer_norm_regs<ND>(xv, g, b);
-            layer_norm_regs<ND>(xv, g2, b2);
+            layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
+            layer_norm_regs<ND>(xv, g2, b2, A.ln_one_pass != 0);
             if (wg == 0 && wave == 0) {
 #pragma unroll
                 for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(A.latent_out + i * 256 + lane * 4) = xv[i];
