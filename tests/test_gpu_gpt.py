@@ -338,14 +338,17 @@ def _round_bf16(w):
     return out
 
 
-@pytest.mark.parametrize("model_args,B,Tc,n,mode", [
-    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16"), (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16"),
-    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16_kv"), (gcfg.TINY_MODEL_ARGS, 3, 75, 70, "bf16_kv"),
-    (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16_kv"), (gcfg.DEFAULT_MODEL_ARGS, 8, 13, 12, "bf16_kv")])
-def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n, mode):
+@pytest.mark.parametrize("model_args,B,Tc,n,mode,in_seed", [
+    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16", 110), (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16", 100),
+    (gcfg.TINY_MODEL_ARGS, 8, 75, 40, "bf16_kv", 110), (gcfg.TINY_MODEL_ARGS, 3, 75, 70, "bf16_kv", 109),
+    (gcfg.DEFAULT_MODEL_ARGS, 1, 13, 24, "bf16_kv", 100), (gcfg.DEFAULT_MODEL_ARGS, 8, 13, 12, "bf16_kv", 100)])
+def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n, mode, in_seed):
     """BASELINE configs[3]: bf16 weight storage, optionally a bf16 KV cache (fp32 math).  Because every path uses the same
     rounded values, the oracle run on bf16-rounded weights (and rounding k/v as they enter its cache) is an exact
-    reference: logits <= 1e-4, ids equal wherever the oracle's own top-1/top-2 margin is not at rounding level.
+    reference: logits <= 1e-4, ids EQUAL -- the input seeds are margin-screened on the CPU (tests/screen_rows_seeds.py: every greedy
+    decision of the oracle has a top-1 / top-2 gap >= 2e-3; re-asserted below).  Only the bf16-CACHE cases whose smallest gap is under
+    3e-3 (the 320-decision tiny ones) keep the old rule -- a k or v within 1e-7 of a bf16 rounding boundary lands one bf16 ulp apart
+    and can move a logit by a few 1e-4: there a flip is accepted where the oracle's own gap is < 1e-3.
     Covers the GEMV decode (B <= 4: fused short-context attention, then split-key past 128 keys), the rows path (B = 8)
     and the prefill scatter."""
     from genvc_amd.engine import GptEngine
@@ -358,15 +361,19 @@ def test_bf16_weight_mode_matches_oracle_on_rounded_weights(model_args, B, Tc, n
     eng.bind(w)
     wr = _round_bf16({k: v.cpu() for k, v in w.items()})
     dims = dict(dims, kv_bf16=mode == "bf16_kv")
-    cond = synth.uniform(51, "cond_latents", (B, 32, dims["d_model"]), 1.0)
-    codes = synth.integers(51, "content_codes", (B, Tc), 256)
+    cond = synth.uniform(in_seed, "cond_latents", (B, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(in_seed, "content_codes", (B, Tc), 256)
     _, toks, lats = run_generate(eng, dims, cond, codes, n)
     ref_t, ref_l, ref_logits = O.generate(wr, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
     pen = [O.process_logits(ref_logits[i], torch.cat([torch.ones(B, 32 + Tc + 2, dtype=torch.long),
                                                        torch.full((B, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
            for i in range(n)]
     margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)      # [B, n]
+    floor = float(margins.min())
+    assert floor >= 2e-3, f"input seed {in_seed} is not margin-screened any more: {floor:.2e}"
     agree = toks.long() == ref_t
+    if mode == "bf16" or floor >= 3e-3:
+        assert bool(agree.all()), "ids differ from the oracle on a margin-screened input"
     for b in range(B):
         bad = (~agree[b]).nonzero()
         if len(bad):                                  # a flip is only acceptable at a near-tie of the oracle itself

@@ -55,19 +55,21 @@ def test_rows_step_batched_decode_vs_oracle(B, H):
     eng.close()
 
 
-@pytest.mark.parametrize("B,Tc,n,H", [(6, 120, 24, 4), (12, 150, 20, 4), (5, 300, 16, 4), (16, 300, 12, 4), (6, 120, 16, 16), (12, 300, 10, 16),
-                                      (7, 300, 10, 8)],
+@pytest.mark.parametrize("B,Tc,n,H,in_seed", [(6, 120, 24, 4, 103), (12, 150, 20, 4, 106), (5, 300, 16, 4, 101), (16, 300, 12, 4, 102),
+                                              (6, 120, 16, 16, 102), (12, 300, 10, 16, 100), (7, 300, 10, 8, 101)],
                          ids=["8rows_2chunks", "16rows_2chunks", "8rows_4chunks", "16rows_4chunks", "8rows_2chunks_16heads", "16rows_4chunks_16heads",
                               "8rows_4chunks_8heads"])
-def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n, H):
+def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n, H, in_seed):
     """contexts past 128 / 288 cached positions: the keys of a (row, head) are split over 2 / 4 workgroups and phase C merges the
-    chunk partials; greedy ids against the oracle wherever the oracle's own top-1 / top-2 margin is not at rounding level"""
+    chunk partials; greedy ids EQUAL to the oracle's.  The input seeds are margin-screened on the CPU (python tests/screen_rows_seeds.py:
+    every greedy decision of the oracle, over all streams and steps, has a top-1 / top-2 gap >= 3e-3 -- the screen the reference
+    fixtures get) and the screen is re-asserted here, so no flip is tolerated."""
     from test_gpu_gpt import run_generate
     from oracle import genvc_oracle as O
     dims, w, eng = _engine(dict(WIDE2, gpt_n_heads=H), 31, max(B, 8))
     wc = {k: v.cpu() for k, v in w.items()}
-    cond = synth.uniform(31, "cond", (B, 32, 1024), 1.0)
-    codes = synth.integers(31, "codes", (B, Tc), 256)
+    cond = synth.uniform(in_seed, "cond", (B, 32, 1024), 1.0)
+    codes = synth.integers(in_seed, "codes", (B, Tc), 256)
     _, toks, lats = run_generate(eng, dims, cond, codes, n)
     assert eng.decode_variant() == 5
     ref_t, ref_l, ref_logits = O.generate(wc, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
@@ -75,14 +77,9 @@ def test_rows_step_long_context_key_chunks_vs_oracle(B, Tc, n, H):
                                                        torch.full((B, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
            for i in range(n)]
     margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)
-    agree = toks.long() == ref_t
-    for b in range(B):
-        bad = (~agree[b]).nonzero()
-        if len(bad):
-            assert float(margins[b, int(bad[0])]) < 1e-3, (b, int(bad[0]), float(margins[b, int(bad[0])]))
-    assert agree.float().mean() > 0.9
-    first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
-    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-4)
+    assert float(margins.min()) >= 2e-3, f"input seed {in_seed} is not margin-screened any more: {float(margins.min()):.2e}"
+    assert torch.equal(toks.long(), ref_t)
+    np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=2e-4)
     eng.close()
 
 
@@ -332,19 +329,20 @@ def test_topk50_sampling_full_size_vs_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("B,Tc,n,mode", [(8, 13, 24, "bf16"), (8, 13, 24, "bf16_kv"), (12, 150, 20, "bf16_kv"), (3, 300, 12, "bf16")],
+@pytest.mark.parametrize("B,Tc,n,mode,in_seed", [(8, 13, 24, "bf16", 102), (8, 13, 24, "bf16_kv", 100), (12, 150, 20, "bf16_kv", 102), (3, 300, 12, "bf16", 100)],
                          ids=["8_streams_bf16", "8_streams_bf16_kv", "16_rows_2_chunks_bf16_kv", "8_rows_4_chunks_bf16"])
-def test_rows_step_bf16_storage_vs_oracle_on_rounded_weights(B, Tc, n, mode):
+def test_rows_step_bf16_storage_vs_oracle_on_rounded_weights(B, Tc, n, mode, in_seed):
     """BASELINE configs[3] (bf16 weight storage, optionally a bf16 KV cache, fp32 arithmetic) on the one-launch rows step: the ring
     holds bf16 weight quads widened in registers, k / v are rounded where they enter the cache and the step's own attention reads
-    the rounded values -- so the oracle on bf16-rounded weights (rounding k / v as they enter ITS cache) is the reference"""
+    the rounded values -- so the oracle on bf16-rounded weights (rounding k / v as they enter ITS cache) is the reference.  Input seeds
+    margin-screened on the CPU (tests/screen_rows_seeds.py, smallest greedy gap >= 3e-3), screen re-asserted: ids must be EQUAL."""
     from test_gpu_gpt import run_generate, _round_bf16
     from oracle import genvc_oracle as O
     dims, w, eng = _engine(WIDE2, 5, max(B, 8), weight_dtype=mode)
     wr = _round_bf16({k: v.cpu() for k, v in w.items()})
     dims = dict(dims, kv_bf16=mode == "bf16_kv")
-    cond = synth.uniform(51, "cond_latents", (B, 32, dims["d_model"]), 1.0)
-    codes = synth.integers(51, "content_codes", (B, Tc), 256)
+    cond = synth.uniform(in_seed, "cond_latents", (B, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(in_seed, "content_codes", (B, Tc), 256)
     _, toks, lats = run_generate(eng, dims, cond, codes, n)
     assert eng.decode_variant() == 5
     ref_t, ref_l, ref_logits = O.generate(wr, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
@@ -352,32 +350,28 @@ def test_rows_step_bf16_storage_vs_oracle_on_rounded_weights(B, Tc, n, mode):
                                                        torch.full((B, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
            for i in range(n)]
     margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)
-    agree = toks.long() == ref_t
-    for b in range(B):
-        bad = (~agree[b]).nonzero()
-        if len(bad):
-            assert float(margins[b, int(bad[0])]) < 1e-3, (b, int(bad[0]), float(margins[b, int(bad[0])]))
-    assert agree.float().mean() > 0.9
-    first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
-    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
+    assert float(margins.min()) >= 2e-3, f"input seed {in_seed} is not margin-screened any more: {float(margins.min()):.2e}"
+    assert torch.equal(toks.long(), ref_t)
+    np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
     eng.close()
 
 
-@pytest.mark.parametrize("d,H,Tc,n,mode", [(1024, 4, 13, 30, "bf16"), (1024, 4, 13, 30, "bf16_kv"), (1024, 4, 150, 24, "bf16_kv"),
-                                           (512, 4, 120, 24, "bf16_kv"), (512, 2, 13, 40, "bf16")],
+@pytest.mark.parametrize("d,H,Tc,n,mode,in_seed", [(1024, 4, 13, 30, "bf16", 100), (1024, 4, 13, 30, "bf16_kv", 100), (1024, 4, 150, 24, "bf16_kv", 100),
+                                                   (512, 4, 120, 24, "bf16_kv", 102), (512, 2, 13, 40, "bf16", 100)],
                          ids=["fused_attention_bf16", "fused_attention_bf16_kv", "key_chunks_bf16_kv", "d512_hd128_bf16_kv", "d512_hd256_bf16"])
-def test_one_stream_step_bf16_storage_vs_oracle_on_rounded_weights(d, H, Tc, n, mode):
+def test_one_stream_step_bf16_storage_vs_oracle_on_rounded_weights(d, H, Tc, n, mode, in_seed):
     """VERDICT round 2, missing 4: the one-launch step of ONE stream with bf16 weight storage (the loader streams bf16 rows, half
     the bytes per phase, widened in registers) and a bf16 KV cache -- short contexts (fused attention + c_proj phase), contexts
-    past 80 keys (key chunks over workgroups), d_model 512 with head_dim 128 and 256 -- against the oracle on rounded weights"""
+    past 80 keys (key chunks over workgroups), d_model 512 with head_dim 128 and 256 -- against the oracle on rounded weights.  Input
+    seeds margin-screened on the CPU (tests/screen_rows_seeds.py: smallest greedy gap >= 1e-2), screen re-asserted: ids must be EQUAL."""
     from test_gpu_gpt import run_generate, _round_bf16
     from oracle import genvc_oracle as O
     margs = dict(gcfg.DEFAULT_MODEL_ARGS, gpt_layers=2, gpt_n_model_channels=d, gpt_n_heads=H)
     dims, w, eng = _engine(margs, 5, 8, weight_dtype=mode)
     wr = _round_bf16({k: v.cpu() for k, v in w.items()})
     dims = dict(dims, kv_bf16=mode == "bf16_kv")
-    cond = synth.uniform(51, "cond_latents", (1, 32, d), 1.0)
-    codes = synth.integers(51, "content_codes", (1, Tc), 256)
+    cond = synth.uniform(in_seed, "cond_latents", (1, 32, d), 1.0)
+    codes = synth.integers(in_seed, "content_codes", (1, Tc), 256)
     _, toks, lats = run_generate(eng, dims, cond, codes, n)
     assert eng.decode_variant() == 3, "bf16 storage did not run on the one-launch step"
     ref_t, ref_l, ref_logits = O.generate(wr, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
@@ -385,13 +379,9 @@ def test_one_stream_step_bf16_storage_vs_oracle_on_rounded_weights(d, H, Tc, n, 
                                                        torch.full((1, 1), 1024), ref_t[:, :i]], 1), 2.0, 1.0, 0, 1.0)
            for i in range(n)]
     margins = torch.stack([p.topk(2, -1)[0][:, 0] - p.topk(2, -1)[0][:, 1] for p in pen], 1)
-    agree = toks.long() == ref_t
-    bad = (~agree[0]).nonzero()
-    if len(bad):
-        assert float(margins[0, int(bad[0])]) < 1e-3, (int(bad[0]), float(margins[0, int(bad[0])]))
-    first = int(bad[0]) if len(bad) else n
-    assert first >= n // 2
-    np.testing.assert_allclose(lats[:, :first].numpy(), ref_l[:, :first].numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
+    assert float(margins.min()) >= 2e-3, f"input seed {in_seed} is not margin-screened any more: {float(margins.min()):.2e}"
+    assert torch.equal(toks.long(), ref_t)
+    np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=2e-3 if mode == "bf16_kv" else 2e-4)
     eng.close()
 
 
