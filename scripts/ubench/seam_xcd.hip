@@ -180,7 +180,7 @@ int main() {
     printf("%-22s %-9s %-9s %-7s %-10s %10s   %s\n", "policy(store/load)", "local_KB", "global_KB", "gevery", "stream_kb", "us/phase", "timeouts wrong xcc-mismatch");
     struct Cfg { const char* name; int id; };
     for (int stream_kb : {0, 48}) {
-        for (int gevery : {0, 2, 4}) {
+        for (int gevery : {0, 2}) {      // (every 2nd phase device-wide; other periods would need their own buffer rotation)
             for (int pk : {2, 4, 16}) {
                 for (int pol = 0; pol < 5; ++pol) {
                     Args A;
