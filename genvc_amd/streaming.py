@@ -28,6 +28,7 @@ import torch
 
 from .inference.inference_utils import _sampling_kwargs, _vocode, handle_chunks
 from .engine import sample_params
+from ._lib import GenvcHipError
 
 
 class _Session:
@@ -162,7 +163,7 @@ class StreamSessions:
         th = toks.cpu()                                           # (synchronises: the steps above have run)
         try:
             eng.health()
-        except Exception:
+        except GenvcHipError:
             # a hand-off of the one-launch step timed out (not all workgroups resident, e.g. another context on the GPU): these tokens
             # and latents are garbage and so are the K/V rows the steps appended.  Nothing of this call is kept or vocoded; the library
             # has switched the context to the launch-per-phase paths, on which the affected segments are decoded again from their start
