@@ -163,7 +163,9 @@ class StreamSessions:
         th = toks.cpu()                                           # (synchronises: the steps above have run)
         try:
             eng.health()
-        except GenvcHipError:
+        except GenvcHipError as e:
+            if "timed out" not in str(e):          # (a full KV cache, ... : not recoverable by repeating the work)
+                raise
             # a hand-off of the one-launch step timed out (not all workgroups resident, e.g. another context on the GPU): these tokens
             # and latents are garbage and so are the K/V rows the steps appended.  Nothing of this call is kept or vocoded; the library
             # has switched the context to the launch-per-phase paths, on which the affected segments are decoded again from their start
