@@ -332,6 +332,103 @@ def make_handle_chunks(seed=19):
     print("handle_chunks:", [out[f"chunk{i}"].shape[0] for i in range(len(lens))])
 
 
+def build_hf_hubert(c, w):
+    """HuggingFace HubertModel (the class fairseq HuBERT / ContentVec checkpoints convert to) loaded with fairseq-named weights"""
+    from transformers import HubertConfig, HubertModel
+    hc = HubertConfig(hidden_size=c["embed_dim"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                      intermediate_size=c["ffn_dim"], conv_dim=tuple(x[0] for x in c["conv_layers"]),
+                      conv_kernel=tuple(x[1] for x in c["conv_layers"]), conv_stride=tuple(x[2] for x in c["conv_layers"]),
+                      num_conv_pos_embeddings=c["pos_conv_kernel"], num_conv_pos_embedding_groups=c["pos_conv_groups"],
+                      feat_extract_norm="group", do_stable_layer_norm=False, hidden_act="gelu", conv_bias=False,
+                      apply_spec_augment=False, layer_norm_eps=1e-5)
+    m = HubertModel(hc).eval()
+    sd = {}
+    for k, v in w.items():
+        k2 = k
+        if k.startswith("feature_extractor.conv_layers."):
+            k2 = k.replace(".0.weight", ".conv.weight").replace(".2.weight", ".layer_norm.weight").replace(".2.bias", ".layer_norm.bias")
+        elif k.startswith("layer_norm."):
+            k2 = "feature_projection." + k
+        elif k.startswith("post_extract_proj."):
+            k2 = k.replace("post_extract_proj", "feature_projection.projection")
+        elif k.startswith("encoder.pos_conv.0."):
+            k2 = {"weight_g": "encoder.pos_conv_embed.conv.parametrizations.weight.original0",
+                  "weight_v": "encoder.pos_conv_embed.conv.parametrizations.weight.original1",
+                  "bias": "encoder.pos_conv_embed.conv.bias"}[k.rsplit(".", 1)[1]]
+        elif k.startswith("encoder.layers."):
+            k2 = (k.replace("self_attn_layer_norm", "layer_norm").replace("self_attn.", "attention.")
+                   .replace("fc1.", "feed_forward.intermediate_dense.").replace("fc2.", "feed_forward.output_dense."))
+        elif k.startswith("final_proj."):
+            continue
+        sd[k2] = v
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("masked_spec_embed" in x for x in missing), (missing, unexpected)
+    return m
+
+
+@torch.inference_mode()
+def make_chain(GPT, DiscreteVAE, seed=1, src_seed=402, ref_seed=100, n_chunks=3, n_steps=24, group=8):
+    """The headline chain of bench.py -- inference_utils.synthesize_utt_streaming(seg_len=1.0, stream_chunk_size=8), reference
+    inference/inference_utils.py:135-217 -- composed from the REFERENCE's own classes at full size (GenVC_small dims, the synthetic weights
+    model_init_synthetic(seed=1) loads): GPT.get_style_emb (Perceiver) on the mel of the 3 s reference, per 1 s chunk HubertModel (HF: fairseq is
+    absent) + final_proj -> DiscreteVAE.get_codebook_indices -> GPT.compute_embeddings + GPT2InferenceModel driven step by step with HF's logits
+    processors (stream_generator.py cannot be imported: see ref_greedy) for a 24-token budget -> groups of 8 latents -> F.interpolate(x4, linear)
+    + HiFiGAN -> the reference's handle_chunks.  The mel is the oracle's (torchaudio absent: parity unpinned for that stage).
+    Source seed margin-screened (tests/chain_oracle.py); the screen is stored."""
+    from oracle import genvc_oracle as O
+    from genvc_amd.utils import DEFAULT_MEL_NORM_FILE, load_mel_norms
+    stub = types.ModuleType("nnAudio"); stub.features = types.ModuleType("nnAudio.features")
+    sys.modules["nnAudio"], sys.modules["nnAudio.features"] = stub, stub.features
+    from layers.hifigan import HiFiGAN
+    from inference.inference_utils import handle_chunks as ref_handle_chunks
+    cfg = gcfg.default_config()
+    dims = gcfg.gpt_dims(cfg.model_args)
+    g = build_ref_gpt(GPT, cfg.model_args, synth.make_weights(seed, synth.gpt_weight_spec(dims)))
+    c = cfg.content_dvae_config
+    dv = DiscreteVAE(channels=c["num_channels"], normalization=None, positional_dims=1, num_tokens=c["num_tokens"],
+                     codebook_dim=c["codebook_dim"], hidden_dim=c["hidden_dim"], num_resnet_blocks=c["num_resnet_blocks"],
+                     kernel_size=c["kernel_size"], num_layers=c["num_layers"], use_transposed_convs=False)
+    missing, unexpected = dv.load_state_dict(synth.make_weights(seed, synth.dvae_weight_spec(c)), strict=False)
+    assert not unexpected
+    dv.eval()
+    hcfg = dict(cfg.hubert_config)
+    hw = synth.make_weights(seed, synth.hubert_weight_spec(hcfg))
+    hub = build_hf_hubert(hcfg, hw)
+    v = cfg.vocoder_config
+    voc = HiFiGAN(v["input_feat_dim"], v["upsample_initial_channel"], v["resblock_kernel_sizes"], v["resblock_dilation_sizes"],
+                  v["upsample_rates"], v["upsample_kernel_sizes"], resblock_type="2")
+    voc.load_state_dict(synth.make_weights(seed, synth.hifigan_weight_spec(v)), strict=True)
+    voc.eval()
+    samp = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
+    src = synth.synth_audio(src_seed, "src", n_chunks * 16000)
+    ref = synth.synth_audio(ref_seed, "ref", 72000)
+    norms = torch.from_numpy(load_mel_norms(DEFAULT_MEL_NORM_FILE))
+    cond = g.get_style_emb(O.mel_spectrogram(ref, norms), None).transpose(1, 2)          # one 3 s chunk: the mean over chunks is itself
+    toks, lats, codes_all, margins, pred = [], [], [], [], []
+    prev = ov = None
+    for ci in range(n_chunks):
+        seg = src[:, ci * 16000:(ci + 1) * 16000]
+        feat = torch.nn.functional.linear(hub(seg).last_hidden_state, hw["final_proj.weight"], hw["final_proj.bias"])
+        codes = dv.get_codebook_indices(feat.transpose(1, 2))
+        r = ref_greedy(g, cond, codes, n_steps, samp)
+        assert r["tokens"].shape[1] == n_steps, "the reference stopped early: pick another seed"
+        codes_all.append(codes.numpy()); toks.append(r["tokens"]); lats.append(r["latents"]); margins.append(r["margins"])
+        for g0 in range(0, n_steps, group):
+            lat = torch.from_numpy(r["latents"][:, g0:g0 + group])
+            mel_in = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[4.0], mode="linear")
+            wav = voc(mel_in).squeeze()
+            chunk, prev, ov = ref_handle_chunks(wav.clone(), prev, ov, 1024)
+            pred.append(chunk.numpy().copy())
+    wav = np.concatenate(pred)
+    tok = np.concatenate(toks, 1)
+    lat = np.concatenate(lats, 1)
+    mg = np.concatenate(margins, 1)
+    np.savez_compressed(os.path.join(GOLD, "chain_full.npz"), seed=seed, src_seed=src_seed, ref_seed=ref_seed, n_steps=n_steps, group=group,
+                        codes=np.concatenate(codes_all, 0), tokens=tok, margins=mg, latents_slice=lat[:, :, :32],
+                        cond_slice=cond.numpy()[:, :, :16], wav_len=wav.shape[0], wav_head=wav[:4096], wav_stride16=wav[::16])
+    print(f"chain_full: {tok.shape[1]} tokens in {n_chunks} chunks, min margin {mg.min():.3e}, wav {wav.shape[0]} samples, rms {np.sqrt((wav ** 2).mean()):.4f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -372,6 +469,8 @@ def main():
         make_hubert()
     if want("chunks"):
         make_handle_chunks()
+    if want("chain"):
+        make_chain(GPT, DiscreteVAE)
 
 
 if __name__ == "__main__":

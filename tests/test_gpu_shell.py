@@ -143,7 +143,7 @@ def test_harnesses_match_the_oracle_driven_through_the_same_segmentation():
     _m.clear()
 
 
-def test_headline_chain_full_size_vs_oracle():
+def test_headline_chain_full_size_vs_oracle(gold):
     """the EXACT chain bench.py times, at GenVC_small's size (L = 30, d = 1024): synthesize_utt_streaming(seg_len=1.0,
     stream_chunk_size=8) on a 3 s source = per 1 s chunk ContentVec -> DVAE/VQ -> prefix -> prefill (chunk 1: 48 rows; chunks 2, 3:
     the 16 uncached rows on the one-launch rows step, conditioning rows cached) -> 24 one-launch decode steps -> vocoder per 8
@@ -174,6 +174,14 @@ def test_headline_chain_full_size_vs_oracle():
     np.testing.assert_allclose(torch.cat(st["latents"], 1).cpu().numpy(), torch.cat(ex["latents"], 1).numpy(), atol=2e-4)
     assert st["wav"].shape == ex["wav"].shape == (9 * 7168,)
     np.testing.assert_allclose(st["wav"].cpu().numpy(), ex["wav"].numpy(), atol=1e-3)
+    # ... and against the same chain composed from the REFERENCE's own classes (tests/golden/chain_full.npz, oracle/make_golden.py:make_chain)
+    g = gold("chain_full")
+    assert int(g["src_seed"]) == 402 and int(g["ref_seed"]) == 100 and int(g["seed"]) == 1
+    assert np.array_equal(torch.cat(st["tokens"], 1).cpu().numpy(), g["tokens"]), "ids differ from the reference classes' chain"
+    np.testing.assert_allclose(torch.cat(st["latents"], 1).cpu().numpy()[:, :, :32], g["latents_slice"], atol=2e-4)
+    wav_h = st["wav"].cpu().numpy()
+    np.testing.assert_allclose(wav_h[:4096], g["wav_head"], atol=1e-3)
+    np.testing.assert_allclose(wav_h[::16], g["wav_stride16"], atol=1e-3)
     # the stages in front of the GPT, one by one
     np.testing.assert_allclose(m.get_gpt_cond_latents(ref.to(DEV), 24000).cpu().numpy(), ex["cond"].numpy(), atol=2e-4)
     for c in range(3):

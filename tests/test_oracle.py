@@ -224,3 +224,27 @@ def test_resampler_restatement_on_band_limited_signals(orig, new):
     a = O.resample(x2, orig, new)
     np.testing.assert_allclose(O.resample(2.5 * x2, orig, new).numpy(), 2.5 * a.numpy(), atol=1e-6)
     np.testing.assert_allclose(loader_resample(x2, orig, new).numpy(), a.numpy(), atol=1e-6)
+
+
+def test_streaming_chain_full_size_vs_reference_classes(gold):
+    """the ORACLE driven through the streaming harness at GenVC_small size (tests/chain_oracle.py: what the GPU test of the headline
+    chain compares with) against the same chain composed from the REFERENCE's own classes (oracle/make_golden.py:make_chain: reference
+    Perceiver / DVAE / GPT / HiFi-GAN / handle_chunks, HuggingFace HubertModel for ContentVec): codes and tokens equal, latents and the
+    cross-faded waveform within float rounding.  Pins the composition -- segmentation, 24-token budget, groups of 8, x4 interpolation,
+    cross-fade -- and not only the stages."""
+    from chain_oracle import streaming_chain, synthetic_bundle
+    g = gold("chain_full")
+    cfg = gcfg.default_config()
+    W = synthetic_bundle(cfg, int(g["seed"]), int(g["n_steps"]))
+    src = synth.synth_audio(int(g["src_seed"]), "src", 48000)
+    ref = synth.synth_audio(int(g["ref_seed"]), "ref", 72000)
+    ex = streaming_chain(W, src, ref, 1.0, int(g["group"]))
+    assert float(g["margins"].min()) >= 2e-3 and ex["token_margin"] >= 2e-3          # margin-screened source seed (both sides)
+    assert np.array_equal(torch.cat(ex["codes"], 0).numpy(), g["codes"])
+    assert np.array_equal(torch.cat(ex["tokens"], 1).numpy(), g["tokens"])
+    np.testing.assert_allclose(ex["cond"].numpy()[:, :, :16], g["cond_slice"], atol=5e-5)
+    np.testing.assert_allclose(torch.cat(ex["latents"], 1).numpy()[:, :, :32], g["latents_slice"], atol=1e-4)
+    wav = ex["wav"].numpy()
+    assert wav.shape[0] == int(g["wav_len"])
+    np.testing.assert_allclose(wav[:4096], g["wav_head"], atol=1e-4)
+    np.testing.assert_allclose(wav[::16], g["wav_stride16"], atol=1e-4)
