@@ -629,7 +629,8 @@ def main():
             fresh()
             step_us, n = wl.eng.time_kernel(7, s1, tok, 24)
             s_mid = wl.P + 1 + 12
-            kern.append({"kernel": f"k_decode_persist<{wl.dims['d_model'] // 256}> (whole decode step of one stream, one launch)", "avg_us": step_us,
+            kern.append({"kernel": f"k_decode_persist<{wl.dims['d_model'] // 256}> (whole decode step of one stream, one launch; instantiation "
+                                   f"<{wl.dims['d_model'] // 256}, {int(wb == 2)}, {int(kvb == 2)}, XL>: the MLP's hidden units stay inside their XCD at d_model 1024)", "avg_us": step_us,
                          "launches_per_step": 1, "bytes": step_bytes(wl.dims, s_mid, wb, kvb)})
             dom = 0
         else:
