@@ -9,7 +9,8 @@ refuses to start when fewer than N GPUs are visible.  Launched BY torch.distribu
 Workload (BASELINE.json configs[1]): GenVC_small streaming, 1 s chunks, top_k=1, batch 1 per GPU.
 A "step" = one synthetic utterance (10 s source @16 kHz, 3 s reference @24 kHz) pushed through the hot
 path exactly as inference_utils.synthesize_utt_streaming orders it:
-    reference wav -> log-mel -> Perceiver -> 32 conditioning latents                     (once)
+    reference wav -> log-mel -> Perceiver -> 32 conditioning latents                     (once; on a second stream beside the
+                                                                                          first chunk's ContentVec + DVAE: independent chains)
     per 1 s chunk: ContentVec (HuBERT-base, 16000 samples -> 49 frames) -> DVAE encoder + VQ -> prefix embeddings
                    -> prefill (48 rows)
                    -> 24 x (sample, KV-cached decode step) in groups of 8 tokens, each group followed by the
@@ -126,13 +127,18 @@ class Workload:
         m, eng = self.model, self.eng
         if record:
             self.ev[0].record()
-        cond = m.get_gpt_cond_latents(self.ref[u % 4], 24000)                          # mel + Perceiver
-        if self.S > 1:
-            cond = cond.expand(self.S, -1, -1).contiguous()                            # one reference speaker for the batch
+        # mel + Perceiver of the reference speaker on a second stream, beside the first chunk's ContentVec + DVAE (as the harness does:
+        # inference_utils.synthesize_utt_streaming; the two chains are independent)
+        cond_future = m.get_gpt_cond_latents_async(self.ref[u % 4], 24000)
+        cond = None
         src = self.src[u % 4]
         for c in range(self.n_chunks):
             feat = m.content_extractor.extract_content_features(src[c])                # ContentVec [S,49,256]
             codes = m.content_dvae._engine.encode(feat, frames_major=True)             # DVAE + VQ (int32 [1,13])
+            if cond is None:
+                cond = cond_future.result()
+                if self.S > 1:
+                    cond = cond.expand(self.S, -1, -1).contiguous()                    # one reference speaker for the batch
             prefix = eng.prefix_embeddings(cond, codes)
             self.ids.fill_(1)
             self.ids[:, self.P] = self.dims["start_audio_token"]

@@ -120,11 +120,16 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
     latency = None
     src_wav = src_wav.to(m.device)
     seg = int(seg_len * m.content_sample_rate)
-    cond_latent = m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
+    # the reference computes the conditioning latents first (:152-153); they do not depend on the source, so here their mel + Perceiver
+    # chain runs on a second stream beside the first segment's ContentVec + DVAE chain (same arithmetic, shorter first-chunk latency)
+    cond_future = m.get_gpt_cond_latents_async(tgt_audio.to(m.device), m.config.audio.sample_rate) if hasattr(m, "get_gpt_cond_latents_async") else None
+    cond_latent = None if cond_future is not None else m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
     cached = 0          # prefix caching: after the first segment the conditioning rows are already in the KV cache
     for src_seg in segments(src_wav, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
         codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+        if cond_latent is None:
+            cond_latent = cond_future.result()
         fake = m.gpt.compute_embeddings(cond_latent, codes)
         gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,
                                   output_hidden_states=True, stream_group=max(stream_chunk_size, 1),

@@ -75,6 +75,13 @@ class GenVCModel(nn.Module):
             embs.append(self.gpt.get_style_emb(mel, None))
         return torch.stack(embs).mean(dim=0).transpose(1, 2).contiguous()
 
+    def get_gpt_cond_latents_async(self, audio, sr, length=30, chunk_length=6):
+        """get_gpt_cond_latents on a second HIP stream: the reference speaker's mel + Perceiver chain (~25 short launches) does not
+        depend on the source audio, so the streaming harness runs it BESIDE the first segment's ContentVec + DVAE chain instead of
+        in front of it (first-chunk latency; the arithmetic and its order inside each chain are unchanged).  Returns a handle whose
+        .result() makes the caller's current stream wait for the latents and returns them."""
+        return _CondFuture(self, audio, sr, length, chunk_length)
+
     @torch.no_grad()
     def inference(self, src_audio, cond_latent, do_sample=True, top_p=0.85, top_k=15, temperature=0.75, num_beams=1,
                   length_penalty=1.0, repetition_penalty=10.0, output_attentions=False):
@@ -96,6 +103,27 @@ class GenVCModel(nn.Module):
         mel_input = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[self.hifigan_scale_factor],
                                                     mode="linear").squeeze(1)
         return self.hifigan.forward(mel_input)
+
+
+class _CondFuture:
+    def __init__(self, model, audio, sr, length, chunk_length):
+        if not audio.is_cuda:
+            audio = audio.to(model.device)
+        main = torch.cuda.current_stream(audio.device)
+        side = getattr(model, "_cond_stream", None)
+        if side is None:
+            side = model._cond_stream = torch.cuda.Stream(device=audio.device)
+        side.wait_stream(main)                       # (the audio may still be in flight on the caller's stream)
+        audio.record_stream(side)
+        with torch.cuda.stream(side):
+            self.cond = model.get_gpt_cond_latents(audio, sr, length, chunk_length)
+        self.side = side
+
+    def result(self):
+        main = torch.cuda.current_stream(self.cond.device)
+        main.wait_stream(self.side)
+        self.cond.record_stream(main)
+        return self.cond
 
 
 def build_model(config, device, content_extractor=None, hifigan=None, max_slots=8, weight_dtype="fp32"):
