@@ -423,13 +423,18 @@ class Config4:
         ev = self.ev
         if record:
             ev[0].record()
-        cond = m.get_gpt_cond_latents(self.ref, 24000)                    # 6 s + 4 s chunks: mel + Perceiver on 563 + 376 frames, mean
+        # 6 s + 4 s chunks: mel + Perceiver on 563 + 376 frames, mean -- on a second stream beside ContentVec + DVAE (independent chains);
+        # the recorded pass keeps them one after the other so that the per-stage times mean what they say
+        cond_future = None if record else m.get_gpt_cond_latents_async(self.ref, 24000)
+        cond = m.get_gpt_cond_latents(self.ref, 24000) if record else None
         if record:
             ev[1].record()
         feat = m.content_extractor.extract_content_features(self.src)     # [5, 299, 256]
         codes = m.content_dvae._engine.encode(feat, frames_major=True)    # [5, 75]
         if record:
             ev[2].record()
+        if cond is None:
+            cond = cond_future.result()
         condB = cond.expand(B, -1, -1).contiguous()
         prefix = eng.prefix_embeddings(condB, codes)
         P = prefix.shape[1]
