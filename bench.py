@@ -122,8 +122,10 @@ class Workload:
         self.ids_len = torch.zeros(S, device=device, dtype=torch.int32)
         self.fin = torch.zeros(S, device=device, dtype=torch.int32)
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self.keep_codes = None                        # a list: utterance() appends the content codes of every chunk (parity_in_bench)
+        self.t_first = None                           # host clock at the first 8-token group of a `sync_first` utterance
 
-    def utterance(self, u, record=False):
+    def utterance(self, u, record=False, sync_first=False):
         m, eng = self.model, self.eng
         if record:
             self.ev[0].record()
@@ -135,6 +137,8 @@ class Workload:
         for c in range(self.n_chunks):
             feat = m.content_extractor.extract_content_features(src[c])                # ContentVec [S,49,256]
             codes = m.content_dvae._engine.encode(feat, frames_major=True)             # DVAE + VQ (int32 [1,13])
+            if self.keep_codes is not None:
+                self.keep_codes.append(codes.clone())
             if cond is None:
                 cond = cond_future.result()
                 if self.S > 1:
@@ -156,13 +160,18 @@ class Workload:
                 self.wav = m.hifigan.forward_latents(lat_view[:, g:g + GROUP], 4)
                 if record and c == 0 and g == 0:
                     self.ev[1].record()                                                # first 8-token group done
+                if sync_first and c == 0 and g == 0:
+                    torch.cuda.synchronize()
+                    self.t_first = time.perf_counter()
         if record:
             self.ev[2].record()
         return self.toks
 
 
-def cpu_baseline(wl, budget_s=10.0):
-    """The oracle (port) on the host cores, one 1 s chunk at a time (ContentVec, DVAE+VQ, prefix, prefill, 24 steps)."""
+def cpu_baseline(wl, budget_s=10.0, gpu=None):
+    """The oracle (port) on the host cores, one 1 s chunk at a time (ContentVec, DVAE+VQ, prefix, prefill, 24 steps).
+    gpu = (token ids [n_chunks * 24], [content codes per chunk]) of the SAME utterance (src[0], ref[0], greedy) from the timed HIP
+    path: the ids the oracle generates here anyway are compared with them -> `parity_in_bench` (the record checks what it computed)."""
     from oracle import genvc_oracle as O
     m = wl.model
     w = {k[len("gpt."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("gpt.")}
@@ -193,10 +202,12 @@ def cpu_baseline(wl, budget_s=10.0):
     t_ref = time.time() - t0
     src = wl.src[0][:, 0].cpu()
 
+    kept = {}
+
     def chunk(c):
         feat = O.hubert_extract_features(wh, hcfg, src[c:c + 1])
         codes = O.dvae_get_codebook_indices(wd, feat.transpose(1, 2))
-        O.generate(w, dims, cond, codes, greedy, max_new=STEPS_PER_CHUNK, stop_on_eos=False)
+        kept[c] = (codes,) + tuple(O.generate(w, dims, cond, codes, greedy, max_new=STEPS_PER_CHUNK, stop_on_eos=False))
 
     chunk(0)                                   # warm-up
     times = []
@@ -209,7 +220,34 @@ def cpu_baseline(wl, budget_s=10.0):
             break
     t_chunk = sum(times) / len(times)
     utt_s = t_ref + wl.n_chunks * t_chunk
-    return {"value": 1.0 / utt_s, "unit": "utterances/s", "cores": cores, "kind": "port",
+    parity = None
+    if gpu is not None:
+        # (outside the timed chunks) the oracle's ids of every chunk it generated against the HIP path's ids of the same chunk; at a
+        # divergence: the oracle's own top-1 / top-2 margin at that step (penalised scores, as tests/screen_rows_seeds.py measures it)
+        g_toks, g_codes = gpu
+        chunks, eq_tok, eq_codes, first, min_margin = sorted(kept), True, True, None, float("inf")
+        for c in chunks:
+            codes, toks, _lats, logits = kept[c]
+            _, ids0 = O.compute_embeddings(w, dims, cond, codes)
+            got = g_toks[c * STEPS_PER_CHUNK:(c + 1) * STEPS_PER_CHUNK].long()
+            same_codes = bool(torch.equal(codes[0].long(), g_codes[c][0].long().cpu()))
+            eq_codes = eq_codes and same_codes
+            for i in range(toks.shape[1]):
+                sc = O.process_logits(logits[i], torch.cat([ids0, toks[:, :i]], 1), greedy["repetition_penalty"], 1.0, 0, 1.0)
+                t2 = sc.topk(2, -1)[0]
+                mg = float(t2[0, 0] - t2[0, 1])
+                min_margin = min(min_margin, mg)
+                if int(toks[0, i]) != int(got[i]):
+                    eq_tok = False
+                    if first is None:
+                        first = {"chunk": c, "step": i, "oracle_margin": mg, "codes_equal": same_codes}
+                    break
+        parity = {"chunks": len(chunks), "tokens_compared": len(chunks) * STEPS_PER_CHUNK, "tokens_equal": eq_tok, "codes_equal": eq_codes,
+                  "first_divergence": first, "oracle_min_margin": min_margin,
+                  "what": "token ids of utterance 0 from the timed HIP path (ContentVec -> DVAE -> prefill -> 24 greedy steps per chunk) vs the "
+                          "ids the CPU oracle generated for the same chunks in this very run; unscreened input: a divergence at an oracle "
+                          "margin below 1e-3 is a near-tie flip, anything else is a bug"}
+    return {"parity": parity, "value": 1.0 / utt_s, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} of {wl.n_chunks} one-second chunks of one utterance (ContentVec, DVAE+VQ, prefill 48 rows, "
                       f"{STEPS_PER_CHUNK} decode steps each) + mel/Perceiver once; extrapolated to the full utterance",
             "ms_per_chunk": t_chunk * 1e3, "ms_per_chunk_min_max": [min(times) * 1e3, max(times) * 1e3],
@@ -501,6 +539,39 @@ def config4_leg(wl, rank, world, dist, device, steps=3):
             "decode_step_us": st[3] / c4.n_new * 1e3, "decode_variant": wl.eng.decode_variant()}
 
 
+def cold_probe(device, rank, weights, max_slots):
+    """First-chunk latency of the FIRST utterance after model_init (host clock from the call to the first vocoder chunk, device
+    synchronised; inputs resident): once on a fresh model as it comes out of model_init, once on a fresh model after
+    GenVCModel.warmup() (include/genvc_hip.h: gvc_gpt_warmup).  `gpt_lazy_inits_*`: allocations / device syncs / graph captures the
+    GPT context did inside data-path calls of that first utterance (0 after the warm-up: SURVEY.md 8(b)(iii)).  Returns the numbers
+    and the warmed-up workload, which the rest of the bench goes on to use."""
+    out = {}
+    t0 = time.perf_counter()
+    wl = Workload(device, rank, 1, weights, max_slots=8)
+    torch.cuda.synchronize()
+    out["model_init_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wl.utterance(0, sync_first=True)
+    out["cold_first_chunk_latency_ms_no_warmup"] = (wl.t_first - t0) * 1e3
+    torch.cuda.synchronize()
+    out["gpt_lazy_inits_no_warmup"] = wl.eng.lazy_inits()
+    del wl
+    torch.cuda.empty_cache()
+    wl = Workload(device, rank, 1, weights, max_slots=max_slots)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.model.warmup(seg_len=CHUNK_SECONDS, streams=1, ref_seconds=REF_SECONDS, stream_chunk_size=GROUP, top_k=1, max_new_tokens=STEPS_PER_CHUNK)
+    out["warmup_call_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wl.utterance(0, sync_first=True)
+    out["cold_first_chunk_latency_ms"] = (wl.t_first - t0) * 1e3
+    torch.cuda.synchronize()
+    out["gpt_lazy_inits_after_warmup"] = wl.eng.lazy_inits()
+    out["window"] = ("first utterance after model_init: host clock from the call (inputs resident in HBM) to the first 8-token vocoder "
+                     "chunk, device synchronised; `cold_first_chunk_latency_ms` = after GenVCModel.warmup(), `..._no_warmup` = without")
+    return out, wl
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher: become `torch.distributed.run` with one rank per GPU"""
     import socket
@@ -529,6 +600,7 @@ def main():
     ap.add_argument("--no-offline", action="store_true", help="skip the batched-offline leg (BASELINE configs[2])")
     ap.add_argument("--no-harness", action="store_true", help="skip the harness-level leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] / prefill legs")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-start probe (first utterance after model_init, with / without warm-up)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
     ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv"],
                     help="GPT weight / KV-cache storage (fp32 = headline configuration; bf16_kv with --streams 8 = BASELINE configs[3])")
@@ -569,7 +641,11 @@ def main():
     # (layers/gpt.py generate_groups), so every rank needs that many slots whatever the world size -- the per-rank path at N > 1
     # must be the one N = 1 is measured on; N = 1 also runs the fully batched figure (one class of OFFLINE_UTTS streams at a time)
     slots_needed = max(16, OFFLINE_SEGMENTS * OFFLINE_MICRO_BATCH, OFFLINE_UTTS if (do_offline and world == 1) else 0)
-    wl = Workload(device, rank, args.streams, args.weights, max_slots=slots_needed)
+    cold = None
+    if world == 1 and headline and not args.no_cold:
+        cold, wl = cold_probe(device, rank, args.weights, slots_needed)
+    else:
+        wl = Workload(device, rank, args.streams, args.weights, max_slots=slots_needed)
     for u in range(args.warmup):
         wl.utterance(u)
 
@@ -703,8 +779,20 @@ def main():
             out["prefill_5x110"] = prefill_leg(wl)
         if headline and not args.no_harness:
             out["harness"] = harness_leg(wl)
+        if cold is not None:
+            out["cold_start"] = cold
+            out["cold_first_chunk_latency_ms"] = cold["cold_first_chunk_latency_ms"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            gpu = None
+            if headline:                        # the ids of utterance 0 (src[0], ref[0]) from the timed path, for parity_in_bench
+                wl.keep_codes = []
+                g_toks = wl.utterance(0)[0].clone()
+                torch.cuda.synchronize()
+                gpu = (g_toks.cpu(), wl.keep_codes)
+                wl.keep_codes = None
+            cb = cpu_baseline(wl, gpu=gpu)
+            out["parity_in_bench"] = cb.pop("parity")
+            out["cpu_baseline"] = cb
         if do_extra and world == 1:
             out["streams8_bf16_kv"] = streams_leg(device, rank)
         print(json.dumps(out))

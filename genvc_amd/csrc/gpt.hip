@@ -279,6 +279,11 @@ struct gvc_gpt {
     size_t r_lds = 0;
     int rows_keys_hint = 0;           // cached positions the longest stream of the running call reaches (set by the entry points)
     int r_split1 = 0, r_split2 = 0;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
+    int p_xl = 1;                     // the one-stream step keeps the MLP's hidden units inside their XCD (GVC_PERSIST_XCD=0: never); cleared by
+                                      // persist_prepare when the device does not deal a 256-workgroup grid as 8 XCDs x 32
+    int arch_xcc = 0;                 // gcnArchName is gfx94x / gfx950: HW_REG_XCC_ID exists and means what the XL layout assumes
+    long long lazy_inits = 0;         // allocations / device-wide syncs / graph captures done INSIDE a data-path call (gvc_gpt_lazy_inits)
+    int in_warmup = 0;                // ... gvc_gpt_warmup's own do not count
 };
 
 static int gemv_init();
@@ -307,6 +312,8 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipGetDevice(&dev));
     GVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->arch_xcc = strncmp(prop.gcnArchName, "gfx950", 6) == 0 || strncmp(prop.gcnArchName, "gfx94", 5) == 0;
+    c->p_xl = getenv("GVC_PERSIST_XCD") ? atoi(getenv("GVC_PERSIST_XCD")) : 1;
 
     const size_t d = D.d_model, L = D.n_layer, V = D.vocab;
     const size_t per_layer = 2 * d + 3 * d * d + 3 * d + d * d + d + 2 * d + 4 * d * d + 4 * d + 4 * d * d + d;
@@ -665,9 +672,9 @@ static int persist_test_grid() {
 typedef void (*persist_fn)(const PersistArgs);
 static persist_fn persist_kernel(const gvc_gpt* c) {
     const int nd = c->dm.d_model / 256;
-    // GVC_PERSIST_XCD=0: d_model 1024 keeps the device-wide hand-off of the hidden units (the round-3 kernel)
-    static const int xcd_local = getenv("GVC_PERSIST_XCD") ? atoi(getenv("GVC_PERSIST_XCD")) : 1;
-    if (nd == 4 && xcd_local) {
+    // p_xl = 0 (GVC_PERSIST_XCD=0, or a device that does not deal 8 XCDs x 32 workgroups: persist_prepare's probe): d_model 1024 keeps the
+    // device-wide hand-off of the hidden units (the round-3 kernel)
+    if (nd == 4 && c->p_xl) {
         if (c->kv_bf16) return (persist_fn)k_decode_persist<4, 1, 1, 1>;
         if (c->bf16) return (persist_fn)k_decode_persist<4, 1, 0, 1>;
         return (persist_fn)k_decode_persist<4, 0, 0, 1>;
@@ -685,9 +692,48 @@ static bool persist_ok(const gvc_gpt* c, int B) {
            (c->hd == 64 || c->hd == 128 || c->hd == 256) && c->dm.n_layer < 500;
 }
 
+// Topology probe for the XCD-local hand-off (k_decode_persist<4, *, *, 1>): a grid of the one-launch step's own shape (256 workgroups, its
+// threads and LDS, so one per CU), all co-resident (they wait for each other, bounded), each adding itself to its XCD's counter.
+// hist[0..7]: workgroups per XCC_ID; hist[8]: arrivals; hist[9]: workgroups that gave up waiting.
+__global__ __launch_bounds__(gvc::kPThreads) void k_xcd_probe(unsigned* hist) {
+    if (threadIdx.x != 0) return;
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicAdd(hist + (xcc & 7u), 1u);
+    atomicAdd(hist + 8, 1u);
+    for (unsigned i = 0; i < (1u << 20); ++i) {
+        if (__hip_atomic_load(hist + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    atomicAdd(hist + 9, 1u);
+}
+
+// does this device run a 256-workgroup grid of the one-launch step as 8 XCDs x 32 co-resident workgroups?
+static bool xcd_topology_ok(gvc_gpt* c) {
+    if (!c->arch_xcc) return false;
+    unsigned* hist = nullptr;
+    unsigned h[10] = {0};
+    bool ok = hipMalloc((void**)&hist, sizeof(h)) == hipSuccess && hipMemset(hist, 0, sizeof(h)) == hipSuccess &&
+              hipFuncSetAttribute((const void*)k_xcd_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->p_lds) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_xcd_probe, dim3(kPG), dim3(kPThreads), c->p_lds, 0, hist);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (hist) (void)hipFree(hist);
+    (void)hipGetLastError();
+    if (!ok || h[9] != 0 || h[8] != (unsigned)kPG) return false;
+    for (int x = 0; x < 8; ++x)
+        if (h[x] != (unsigned)kPG / 8) return false;
+    return true;
+}
+
+// a data-path call had to allocate / synchronise the device / capture a graph (first use of a path without gvc_gpt_warmup)
+static inline void note_lazy(gvc_gpt* c) { if (!c->in_warmup) c->lazy_inits += 1; }
+
 // buffers and the per-layer pointer table; called outside stream capture (synchronous copies)
 static int persist_prepare(gvc_gpt* c) {
     if (c->p_layers || !c->persist) return GVC_OK;
+    note_lazy(c);
     const int d = c->dm.d_model, L = c->dm.n_layer, H = c->dm.n_head;
     std::vector<PersistLayer> t(L);
     for (int l = 0; l < L; ++l) {
@@ -732,6 +778,9 @@ static int persist_prepare(gvc_gpt* c) {
     while (c->p_ring_slots > 1 && (size_t)c->p_ring_slots * kPSlot + other > (size_t)lds_optin) c->p_ring_slots >>= 1;
     c->p_lds = (size_t)c->p_ring_slots * kPSlot + other;
     if (c->p_lds > (size_t)lds_optin || c->p_ring_slots < 4) return unavailable();
+    // the XCD-local layout assumes 8 XCDs x 32 resident workgroups and HW_REG_XCC_ID: probed once per context, on a grid of the
+    // step's own shape; anything else (CU masking, another partition mode, another part) keeps the device-wide hand-off
+    if (d == 1024 && c->p_xl && !xcd_topology_ok(c)) c->p_xl = 0;
     if (hipFuncSetAttribute((const void*)persist_kernel(c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->p_lds) != hipSuccess)
         return unavailable();
     // one workgroup per CU must fit (registers, LDS): otherwise the one-launch step is switched off for this context
@@ -833,6 +882,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         bool any = false;
         for (char f : c->r_dirty) any = any || f;
         if (any) {
+            note_lazy(c);
             GVC_CHECK_HIP(hipDeviceSynchronize());
             for (int l = 0; l < c->dm.n_layer; ++l)
                 if (c->r_dirty[l]) rows_pack_layer(c, l);
@@ -842,6 +892,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         }
     }
     if (c->r_ready != 0) return GVC_OK;
+    note_lazy(c);
     const int L = c->dm.n_layer;
     c->r_lds = (size_t)8 * kPSlot + ((size_t)kPCW * 4 * kRMaxRows * 4 + 2 * kPCW * 16 + 3 * kRMaxRows * 4 + kPCW * 64 * 4 + 256 + 64 + kPCW * 256) * sizeof(float) +
                kCtlWords * sizeof(unsigned);
@@ -1331,6 +1382,76 @@ static int build_step_graph(gvc_gpt* c, int B, bool fused, int key_chunks, int n
     return GVC_OK;
 }
 
+// What a gvc_gpt_generate call over B streams that reaches `key_bound` cached positions replays: the step variant, its key split and the
+// key of its captured graph.  Runs the one-time preparation of the one-launch steps first (they may switch a path off for this context --
+// r_ready / persist -- so nothing is derived from rows_decode_ok / persist_ok before).
+struct GenPlan {
+    bool fused, greedy;
+    int key_chunks, key, variant;
+};
+
+static int step_unroll() {
+    // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
+    static const int k = getenv("GVC_STEP_UNROLL") ? std::min(32, std::max(1, atoi(getenv("GVC_STEP_UNROLL")))) : 8;   // (<= 32: bits 24..29 of the graph key)
+    return k;
+}
+
+static int plan_generate(gvc_gpt* c, int B, int key_bound, int top_k, GenPlan* pl) {
+    int rc;
+    pl->fused = fused_ok(c, B, key_bound);
+    // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
+    // cached positions on (default 144; 0: never), four beyond 320
+    static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
+    if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
+    if (!persist_ok(c, B) && rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    pl->key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
+                         ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
+    const bool rows1 = !persist_ok(c, B) && c->r_ready == 1 && rows_persist_ok(c, B, c->st.seq_len);      // one-launch rows step
+    c->rows_keys_hint = key_bound;
+    pl->key = B * 2 + (pl->fused ? 1 : 0) + 4096 * (rows1 ? 8 + rows_persist_chunks(c, B, key_bound) : pl->key_chunks);   // (the one-launch steps are pure functions of B [and the key split])
+    pl->variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (pl->fused ? 2 : 1)));
+    // (the sampler kernel is chosen at capture time: a graph serves top_k = 1 or everything else)
+    pl->greedy = sample_greedy_ok(top_k, c->dm.d_model);
+    return GVC_OK;
+}
+
+static int step_graph(gvc_gpt* c, int B, const GenPlan& pl, int unroll, hipGraphExec_t* ge) {
+    const int k = pl.key + (unroll > 1 ? (1 << 24) * unroll : 0) + (pl.greedy ? (1 << 30) : 0);
+    auto it = c->graphs.find(k);
+    if (it == c->graphs.end()) {
+        hipGraphExec_t g1;
+        note_lazy(c);
+        int r = build_step_graph(c, B, pl.fused, pl.key_chunks, unroll, pl.greedy, &g1);
+        if (r) return r;
+        it = c->graphs.emplace(k, g1).first;
+    }
+    *ge = it->second;
+    return GVC_OK;
+}
+
+// Everything a later gvc_gpt_generate / gvc_gpt_decode_step / gvc_gpt_prefill_cached call of this shape would otherwise do on first use:
+// the one-launch steps' buffers, weight pack, topology probe and LDS opt-in, and the captured step graphs (eight steps and one step) for
+// B streams reaching `max_keys` cached positions with this top_k.  Synchronous; call it after the weights are bound, once per shape a
+// deployment uses.  After it, data-path calls of that shape neither allocate nor synchronise the device (gvc_gpt_lazy_inits stays put).
+extern "C" int gvc_gpt_warmup(gvc_gpt* c, int32_t B, int32_t max_keys, int32_t top_k) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && max_keys >= 0 && max_keys < c->dm.max_seq, GVC_ERR_ARG, "warmup: bad argument");
+    c->in_warmup = 1;
+    struct Leave { gvc_gpt* c; ~Leave() { c->in_warmup = 0; } } leave{c};
+    // the rows step also serves the <= 16 uncached rows of a cached chunk prefill, whatever B
+    if (rows_persist_ok(c, 16, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
+    GenPlan pl;
+    if ((rc = plan_generate(c, B, max_keys > 0 ? max_keys : c->dm.max_seq - 1, top_k, &pl))) return rc;
+    hipGraphExec_t ge;
+    if (step_unroll() > 1 && (rc = step_graph(c, B, pl, step_unroll(), &ge))) return rc;
+    if ((rc = step_graph(c, B, pl, 1, &ge))) return rc;
+    GVC_CHECK_HIP(hipDeviceSynchronize());
+    return GVC_OK;
+}
+
+extern "C" long long gvc_gpt_lazy_inits(gvc_gpt* c) { return c ? c->lazy_inits : 0; }
+
 extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                                 int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,
                                 int32_t n_steps, int32_t max_keys, int32_t* tokens_out, int32_t tok_stride, float* latents_out,
@@ -1353,45 +1474,19 @@ extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int
     hipLaunchKernelGGL(k_gen_begin, dim3(B + 1), dim3(256), 0, s, c->gen_call, sc, slots, B, c->step_ctr, c->logits, c->slot_logits,
                        c->dm.vocab, c->latent, c->slot_latent, c->dm.d_model);
     GVC_LAUNCH_CHECK();
-    const bool fused = fused_ok(c, B, key_bound);
-    // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
-    // cached positions on (default 144; 0: never), four beyond 320
-    static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
-    // (the prepare calls may switch a one-launch path off for this context -- r_ready / persist -- so they run before anything is
-    // derived from rows_decode_ok / persist_ok)
-    if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
-    if (!persist_ok(c, B) && rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
-    const int key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)
-                               ? (key_bound > 320 ? 4 : (key_bound > key_split ? 2 : 1)) : 1;
-    const bool rows1 = !persist_ok(c, B) && c->r_ready == 1 && rows_persist_ok(c, B, c->st.seq_len);      // one-launch rows step
-    c->rows_keys_hint = key_bound;
-    const int key = B * 2 + (fused ? 1 : 0) + 4096 * (rows1 ? 8 + rows_persist_chunks(c, B, key_bound) : key_chunks);   // (the one-launch steps are pure functions of B [and the key split])
-    c->last_variant = persist_ok(c, B) ? 3 : (rows1 ? 5 : (rows_decode_ok(c, B) ? 4 : (fused ? 2 : 1)));
-    // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
-    static const int kStepUnroll = getenv("GVC_STEP_UNROLL") ? std::min(32, std::max(1, atoi(getenv("GVC_STEP_UNROLL")))) : 8;   // (<= 32: bits 24..29 of the graph key)
-    // (the sampler kernel is chosen at capture time: a graph serves top_k = 1 or everything else)
-    const bool greedy = sample_greedy_ok(p->top_k, c->dm.d_model);
-    auto graph_of = [&](int unroll, hipGraphExec_t* ge) -> int {
-        const int k = key + (unroll > 1 ? (1 << 24) * unroll : 0) + (greedy ? (1 << 30) : 0);
-        auto it = c->graphs.find(k);
-        if (it == c->graphs.end()) {
-            hipGraphExec_t g1;
-            int r = build_step_graph(c, B, fused, key_chunks, unroll, greedy, &g1);
-            if (r) return r;
-            it = c->graphs.emplace(k, g1).first;
-        }
-        *ge = it->second;
-        return GVC_OK;
-    };
+    GenPlan pl;
+    if ((rc = plan_generate(c, B, key_bound, p->top_k, &pl))) return rc;
+    c->last_variant = pl.variant;
+    const int kStepUnroll = step_unroll();
     int left = n_steps;
     if (kStepUnroll > 1 && left >= kStepUnroll) {
         hipGraphExec_t ge;
-        if ((rc = graph_of(kStepUnroll, &ge))) return rc;
+        if ((rc = step_graph(c, B, pl, kStepUnroll, &ge))) return rc;
         for (; left >= kStepUnroll; left -= kStepUnroll) GVC_CHECK_HIP(hipGraphLaunch(ge, s));
     }
     if (left > 0) {
         hipGraphExec_t ge;
-        if ((rc = graph_of(1, &ge))) return rc;
+        if ((rc = step_graph(c, B, pl, 1, &ge))) return rc;
         for (; left > 0; --left) GVC_CHECK_HIP(hipGraphLaunch(ge, s));
     }
     hipLaunchKernelGGL(k_gen_end, dim3(B), dim3(256), 0, s, slots, c->logits, c->slot_logits, c->dm.vocab, c->latent, c->slot_latent,

@@ -469,6 +469,9 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7u;
         xrank = __hip_atomic_fetch_add(A.epoch + 4 + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // more than 32 workgroups of this grid on one XCD (CU masking, another partition mode, an uneven deal): the XCD-local layout does
+        // not hold.  Reported like a hand-off time-out (the ranks that are missing elsewhere time out anyway): the host drops the call
+        if (xrank >= 32u) __hip_atomic_store(A.err, 961, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
 
@@ -1030,6 +1033,12 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const unsigned prev = __hip_atomic_fetch_add(A.epoch + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (prev == gridDim.x - 1) {
             __hip_atomic_store(A.epoch + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the per-XCD rank counters start every launch at zero: a workgroup's rank is its arrival order inside THIS grid, whatever
+            // earlier launches (other grid sizes, an uneven deal) left behind
+            if (XL) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) __hip_atomic_store(A.epoch + 4 + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __hip_atomic_store(A.epoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

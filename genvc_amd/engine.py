@@ -135,6 +135,15 @@ class GptEngine:
         launch-per-phase paths) or a full KV cache (include/genvc_hip.h: gvc_gpt_health)"""
         check(lib().gvc_gpt_health(self._h), "health")
 
+    def warmup(self, B=1, max_keys=0, top_k=1):
+        """everything the first generate / decode_step / cached prefill of this shape would do on first use (buffers, weight pack,
+        topology probe, step-graph capture); afterwards such calls neither allocate nor synchronise (include/genvc_hip.h: gvc_gpt_warmup)"""
+        check(lib().gvc_gpt_warmup(self._h, int(B), int(max_keys), int(top_k)), "warmup")
+
+    def lazy_inits(self):
+        """allocations / device syncs / graph captures done inside data-path calls so far (include/genvc_hip.h: gvc_gpt_lazy_inits)"""
+        return int(lib().gvc_gpt_lazy_inits(self._h))
+
     def rows_step_launches(self):
         """one-launch rows steps issued so far (include/genvc_hip.h: gvc_gpt_rows_step_launches)"""
         return int(lib().gvc_gpt_rows_step_launches(self._h))

@@ -161,6 +161,8 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
                     latency = time.time() - begin
                     if verbose:
                         print(f"Latency: {latency:.3f}s")
+    if cond_latent is None and cond_future is not None:
+        cond_future.result()          # no segment consumed the latents: still join the side stream (its scratch buffers are per context)
     torch.cuda.synchronize()
     rtf = (time.time() - begin) / (total / m.content_sample_rate)
     if verbose:

@@ -64,6 +64,11 @@ class GenVCModel(nn.Module):
     @torch.inference_mode()
     def get_gpt_cond_latents(self, audio, sr, length=30, chunk_length=6):
         """reference trainers/hifigan_trainer.py:438-455 -> [1, 32, d]"""
+        # a conditioning chain started by get_gpt_cond_latents_async whose result() was never called (no segment, an exception)
+        # may still be running on the side stream with the per-context mel / Perceiver scratch buffers: wait for it first
+        side = getattr(self, "_cond_stream", None)
+        if side is not None and audio.is_cuda and torch.cuda.current_stream(audio.device) != side:
+            torch.cuda.current_stream(audio.device).wait_stream(side)
         embs = []
         if audio.shape[1] > sr * length:
             audio = audio[:, :sr * length]
@@ -81,6 +86,46 @@ class GenVCModel(nn.Module):
         in front of it (first-chunk latency; the arithmetic and its order inside each chain are unchanged).  Returns a handle whose
         .result() makes the caller's current stream wait for the latents and returns them."""
         return _CondFuture(self, audio, sr, length, chunk_length)
+
+    @torch.inference_mode()
+    def warmup(self, seg_len=1.0, streams=1, ref_seconds=3.0, stream_chunk_size=8, top_k=None, max_new_tokens=None):
+        """Everything the FIRST conversion of this shape would otherwise pay inside its latency window (the reference leaves warm-up
+        to the user: /root/reference/infer.py:27-30 runs a conversion first).  For `streams` concurrent streams of `seg_len`-second
+        segments and a `ref_seconds` reference:
+          * GPT context: gvc_gpt_warmup for every context class the generation calls of a segment reach (the one-launch steps' buffers,
+            weight pack and topology probe; the captured step graphs) -- after it no GPT data-path call allocates or synchronises;
+          * ContentVec / DVAE / HiFi-GAN / mel + Perceiver: one pass over zeros of the real shapes (their per-shape graphs and plans).
+        No token is generated and no KV slot is left occupied."""
+        dev = self.device
+        g = self.gpt
+        g._need_engine()
+        eng = g.engine
+        n_src = int(seg_len * self.content_sample_rate)
+        wav = torch.zeros(streams, n_src, device=dev)
+        wav[:, ::7] = 0.01                                   # (not digital silence: the `wav == 0` frame mask must not swallow the input)
+        feat = self.content_extractor.extract_content_features(wav)
+        codes = self.content_dvae.get_codebook_indices(feat.transpose(1, 2))
+        ref = torch.zeros(1, int(ref_seconds * self.config.audio.sample_rate), device=dev)
+        ref[:, ::5] = 0.01
+        cond = self.get_gpt_cond_latents(ref, self.config.audio.sample_rate)
+        n0 = cond.shape[1] + codes.shape[1] + 3
+        top_k = self.config.top_k if top_k is None else top_k
+        max_new = int(max_new_tokens or g.max_gen_mel_tokens)
+        grp = max(stream_chunk_size, 1)
+        seen = set()
+        for done in range(0, max_new, grp):                  # the calls get_generator / _advance will make: max_keys = n0 + done + n
+            mk = min(n0 + done + grp, eng.dims["max_seq"] - 1)
+            cls = (mk <= 128, mk > 144, mk > 320, mk > 80, mk > 160)      # the context classes the library keys its graphs by
+            if cls in seen:
+                continue
+            seen.add(cls)
+            eng.warmup(streams, mk, top_k)
+        if self.hifigan is not None:
+            lat = torch.zeros(streams, grp, g.model_dim, device=dev)
+            for n in {grp, max(1, max_new % grp)}:
+                self.hifigan.forward_latents(lat[:, :n].contiguous(), int(self.hifigan_scale_factor))
+        torch.cuda.synchronize()
+        return self
 
     @torch.no_grad()
     def inference(self, src_audio, cond_latent, do_sample=True, top_p=0.85, top_k=15, temperature=0.75, num_beams=1,

@@ -10,6 +10,7 @@ Training-only paths (losses, masks, eval_sample) raise NotImplementedError: out 
 import torch
 from torch import nn
 
+from .._lib import GenvcHipError
 from ..engine import GptEngine, sample_params
 from .perceiver_encoder import PerceiverResampler
 
@@ -90,6 +91,7 @@ class GPT(nn.Module):
         self.engine = None
         self._prefix = None
         self.max_slots = 8
+        self.recoveries = 0          # generations repeated after a hand-off time-out of a one-launch step (_recovering)
 
     # ------------------------------------------------------------------------------------------
     def dims(self):
@@ -121,6 +123,24 @@ class GPT(nn.Module):
     def _need_engine(self):
         if self.engine is None:
             raise RuntimeError("call init_gpt_for_inference() first (reference inference/model_init.py:31)")
+
+    def _recovering(self, n_slots, fn):
+        """fn() -- a whole generation that has not handed anything to its caller yet -- with ONE retry after a hand-off time-out of a
+        one-launch step (another context held CUs: include/genvc_hip.h, gvc_gpt_health).  The failed attempt's tokens and K/V rows are
+        garbage; the library has already switched this context to the launch-per-phase paths, so the slots are reset and the work is
+        repeated there.  Either the caller gets the tokens of a clean run or the error propagates: never the garbage
+        (reference semantics: a call returns its tokens or fails, /root/reference/inference/inference_utils.py:135-217).  Other
+        state errors (a full KV cache) are not recoverable by repeating and propagate at once."""
+        try:
+            return fn()
+        except GenvcHipError as e:
+            if "timed out" not in str(e):
+                raise
+            self.recoveries = getattr(self, "recoveries", 0) + 1
+            torch.cuda.synchronize()
+            dev = next(self.parameters()).device
+            self.engine.reset(torch.arange(n_slots, device=dev, dtype=torch.int32))
+            return fn()
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
@@ -188,9 +208,17 @@ class GPT(nn.Module):
         `group` (extra kwarg) = decode steps per host check of the finished flags."""
         fake = self.compute_embeddings(cond_latents, text_inputs)
         group = generate_kwargs.pop("group", 16)
-        st = self._start(fake, generate_kwargs)
-        while not self._advance(st, group):
-            pass
+
+        attempt = []
+
+        def run():
+            # (a retry after a hand-off time-out prefills in full: the reset slots have lost any cached conditioning rows)
+            st = self._start(fake, dict(generate_kwargs, cached_cond_rows=0) if attempt else generate_kwargs)
+            attempt.append(1)
+            while not self._advance(st, group):
+                pass
+            return st
+        st = self._recovering(int(fake.shape[0]), run)
         # the reference loop stops at the step where the last row emits 1025
         toks = st["toks"][:, :st["done"]].long()
         n = self._stop_len(toks)
@@ -241,6 +269,10 @@ class GPT(nn.Module):
                 outs.append(self.generate(c, t, **kg))
             self.last_latents = None      # (same contract as the joint path: callers of generate_groups want tokens)
             return outs
+        return self._recovering(total, lambda: self._generate_groups_joint(groups, kw, budgets, group, stats))
+
+    def _generate_groups_joint(self, groups, kw, budgets, group, stats):
+        total = sum(int(t.shape[0]) for _, t in groups)
         if stats is not None:
             stats["joint"] += 1
         dev = groups[0][1].device
@@ -292,12 +324,16 @@ class GPT(nn.Module):
     @torch.inference_mode()
     def generate_rolling(self, jobs, **generate_kwargs):
         """generate_groups with a ROLLING set of streams (greedy decoding only): jobs = [(cond_latents [B_i, 32, d], text_inputs
-        [B_i, Tc_i]), ...] are admitted in order as KV slots become free, and a job leaves the decode when its budget is spent or all
-        its rows have emitted the stop token -- the slots it frees go to the next job at once, so the decode step keeps as many rows as
-        the context has slots instead of draining to the longest class (configs[2]: the 47-step tail of a micro-batch's 6 s class runs
-        beside the NEXT micro-batch's 4 s class).  Streams are independent given their prefix, so every job gets what generate()
-        returns for it (reference gpt.py:594-609 + stream_generator.py:861-874 per row).  `max_new_tokens`: one budget, or a list
-        with one per job.  Returns a list of int64 [B_i, n_i] in job order."""
+        [B_i, Tc_i]), ...] are admitted in order as KV slots become free.  Retirement is PER ROW, as the reference's loop tracks
+        `unfinished_sequences` per row (stream_generator.py:861-874): a row that has emitted the stop token gives its KV slot back at
+        the next host look (every `group` steps) and stops taking a row of the decode step; the rows of a job whose budget is spent
+        leave together.  Freed slots go to the next job as soon as all ITS rows fit, so the decode step stays full instead of
+        draining to the longest stream (configs[2]: the 47-step tail of a micro-batch's 6 s class runs beside the NEXT micro-batch's
+        4 s class; a real checkpoint ends every class ragged).  Streams are independent given their prefix, so every job gets what
+        generate() returns for it: finished rows padded with the stop token up to the step where the job's last row stops
+        (reference gpt.py:594-609).  `max_new_tokens`: one budget, or a list with one per job.  Returns a list of int64 [B_i, n_i]
+        in job order.  `self.rolling_stats` (if the attribute is a dict) accumulates row_steps_issued / row_steps_live: rows x steps
+        the decode calls ran, and how many of them produced a token the reference's loop would have produced."""
         self._need_engine()
         kw = dict(generate_kwargs)
         group = kw.pop("group", 16)
@@ -314,46 +350,54 @@ class GPT(nn.Module):
             budgets = [int(budgets or self.max_gen_mel_tokens)] * len(jobs)
         if not jobs:
             return []
-        dev = jobs[0][1].device
-        eng = self.engine
         n0s = [int(t.shape[1]) + int(c.shape[1]) + 3 for c, t in jobs]            # prefix rows (cond + text + 2) + the start token
         width = max(n0 + b for n0, b in zip(n0s, budgets)) + 8
         S = min(self.max_slots, int(max_rows)) if max_rows else self.max_slots
         if max(int(t.shape[0]) for _, t in jobs) > S:
             raise ValueError(f"generate_rolling: a job has more rows than streams may be in flight ({S}; KV slots {self.max_slots})")
+        return self._recovering(S, lambda: self._rolling(jobs, kw, budgets, group, n0s, width, S))
+
+    def _rolling(self, jobs, kw, budgets, group, n0s, width, S):
+        dev = jobs[0][1].device
+        eng = self.engine
+        stop = self.stop_audio_token
         ids_all = torch.ones(S, width, device=dev, dtype=torch.int32)
         len_all = torch.zeros(S, device=dev, dtype=torch.int32)
         fin_all = torch.zeros(S, device=dev, dtype=torch.int32)
         samp = dict(repetition_penalty=kw.get("repetition_penalty", 1.0), temperature=kw.get("temperature", 1.0),
                     top_p=kw.get("top_p", 1.0), top_k=1)
-        params = sample_params(samp, self.num_audio_tokens, self.stop_audio_token, kw.get("seed", 0))
+        params = sample_params(samp, self.num_audio_tokens, stop, kw.get("seed", 0))
         stats = getattr(self, "groups_stats", None)
+        rstats = getattr(self, "rolling_stats", None)
         free = list(range(S))
         live, out, nxt = [], [None] * len(jobs), 0
         while nxt < len(jobs) or live:
-            # admit jobs in order while their rows fit
+            # admit jobs in order while all their rows fit
             while nxt < len(jobs) and int(jobs[nxt][1].shape[0]) <= len(free):
                 c, t = jobs[nxt]
                 b = int(t.shape[0])
-                sl = torch.tensor(free[:b], device=dev, dtype=torch.int32)
+                mine = free[:b]
                 del free[:b]
+                sl = torch.tensor(mine, device=dev, dtype=torch.int32)
                 prefix = eng.prefix_embeddings(c.to(torch.float32).contiguous(), t.to(torch.int32).contiguous())
                 eng.prefill(sl, prefix, want_outputs=False)
                 idx = sl.long()
-                ids_all[idx] = 1
+                ids_all[idx] = 1                                    # (a reused slot starts with a clean history: repetition_penalty reads it)
                 ids_all[idx, n0s[nxt] - 1] = self.start_audio_token
                 len_all[idx] = n0s[nxt]
                 fin_all[idx] = 0
-                live.append(dict(job=nxt, slots=sl, rows=b, n0=n0s[nxt], budget=budgets[nxt], done=0, toks=[]))
+                live.append(dict(job=nxt, slots=mine, alive=list(range(b)), n0=n0s[nxt], budget=budgets[nxt], done=0,
+                                 toks=torch.full((b, budgets[nxt]), stop, device=dev, dtype=torch.int32)))
                 nxt += 1
             n = min(group, min(j["budget"] - j["done"] for j in live))
-            rows = torch.cat([j["slots"] for j in live])
+            row_slots = [j["slots"][r] for j in live for r in j["alive"]]
+            rows = torch.tensor(row_slots, device=dev, dtype=torch.int32)
             idx = rows.long()
             W = max(j["n0"] + j["done"] for j in live) + n + 8
             ids = ids_all[idx, :W].contiguous()
             ids_len = len_all[idx].contiguous()
             fin = fin_all[idx].contiguous()
-            toks = torch.full((int(rows.shape[0]), n), self.stop_audio_token, device=dev, dtype=torch.int32)
+            toks = torch.full((len(row_slots), n), stop, device=dev, dtype=torch.int32)
             eng.generate(rows, ids, ids_len, fin, params, 0, n, toks, None, max_keys=W - 8)
             ids_all[idx, :W] = ids
             len_all[idx] = ids_len
@@ -362,19 +406,32 @@ class GPT(nn.Module):
             eng.health()
             if stats is not None:
                 stats["joint"] += 1
+            if rstats is not None:
+                th = toks.cpu()
+                hit = th == stop
+                first = torch.where(hit.any(1), hit.int().argmax(1) + 1, torch.full((th.shape[0],), n))
+                rstats["row_steps_issued"] = rstats.get("row_steps_issued", 0) + n * len(row_slots)
+                rstats["row_steps_live"] = rstats.get("row_steps_live", 0) + int(first.sum())
+                rstats["calls"] = rstats.get("calls", 0) + 1
             r = 0
             keep = []
             for j in live:
-                j["toks"].append(toks[r:r + j["rows"]])
+                k = len(j["alive"])
+                a = torch.tensor(j["alive"], device=dev, dtype=torch.long)
+                j["toks"][a, j["done"]:j["done"] + n] = toks[r:r + k]
                 j["done"] += n
-                if j["done"] >= j["budget"] or bool(fin_h[r:r + j["rows"]].all()):
-                    t = torch.cat(j["toks"], 1).long()
+                still = [row for i, row in enumerate(j["alive"]) if not bool(fin_h[r + i])]
+                gone = [row for i, row in enumerate(j["alive"]) if bool(fin_h[r + i])]
+                r += k
+                if j["done"] >= j["budget"] or not still:           # the job is over: its budget is spent or its last row has stopped
+                    t = j["toks"][:, :j["done"]].long()
                     out[j["job"]] = t[:, :self._stop_len(t)]
-                    free.extend(int(v) for v in j["slots"].tolist())
-                    free.sort()
+                    gone = j["alive"]
                 else:
+                    j["alive"] = still
                     keep.append(j)
-                r += j["rows"]
+                free.extend(j["slots"][row] for row in gone)        # a stopped row's slot serves the next job from the next call on
+                free.sort()
             live = keep
         self.last_latents = None
         return out
@@ -393,10 +450,33 @@ class GPT(nn.Module):
         inference_utils.py:195) with one host check of the finished flags per group."""
         self._need_engine()
         group = generate_kwargs.pop("stream_group", 8)
-        st = self._start(fake_inputs, generate_kwargs)
+        B = int(fake_inputs.shape[0])
         emitted = 0
+        st = None
+        retried = False
+
+        def restart():
+            # a hand-off time-out (see _recovering): the segment is generated again from its start on the launch-per-phase paths --
+            # a full prefill (the reset slots have lost their cached conditioning rows) -- and the steps already yielded are skipped:
+            # greedy decoding repeats them (with top_k > 1 what follows comes from a different token sequence)
+            self.recoveries = getattr(self, "recoveries", 0) + 1
+            torch.cuda.synchronize()
+            self.engine.reset(torch.arange(B, device=fake_inputs.device, dtype=torch.int32))
+            s2 = self._start(fake_inputs, dict(generate_kwargs, cached_cond_rows=0))
+            while s2["done"] < emitted and not self._advance(s2, min(group, emitted - s2["done"])):
+                pass
+            return s2
         while True:
-            end = self._advance(st, group)
+            try:
+                if st is None:
+                    st = self._start(fake_inputs, generate_kwargs)
+                end = self._advance(st, group)
+            except GenvcHipError as e:
+                if "timed out" not in str(e) or retried:
+                    raise
+                retried = True
+                st = restart()
+                continue
             toks = st["toks"][:, emitted:st["done"]].long()
             n = toks.shape[1]
             if end and n:

@@ -170,6 +170,10 @@ def convert_offline(model, src_wavs, ref_audio, seg_len=6.0, micro_batch=8, rank
     GPT.generate_groups -- including its `group` (decode steps per host look at the finished flags), which this function's
     process-group parameter used to shadow: with `group=48` in the kwargs every N > 1 run died in the all_gather."""
     m = model
+    g = gen_kwargs.get("group")
+    if g is not None and (isinstance(g, bool) or not isinstance(g, int)):
+        raise TypeError(f"convert_offline: group={g!r} -- `group` is the number of decode steps per host look (an int, passed on to "
+                        "GPT.generate_groups); the torch.distributed process group of the all_gather is `process_group=`")
     cond = m.get_gpt_cond_latents(ref_audio.to(m.device), m.config.audio.sample_rate)
     lengths = [int(w.shape[-1]) for w in src_wavs]
     mine = plan(lengths, rank, world)

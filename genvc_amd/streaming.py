@@ -115,7 +115,45 @@ class StreamSessions:
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def step(self):
-        """advance every open stream by one scheduling step; returns {sid: [wav chunks emitted now]}"""
+        """advance every open stream by one scheduling step; returns {sid: [wav chunks emitted now]}.
+        A hand-off time-out of a one-launch step (another context held CUs) can surface from ANY library call of the step -- the health
+        check after the decode call, but also the entry check of this step's prefill / cached chunk prefill / generate, which reports
+        what the PREVIOUS call left behind.  Wherever it surfaces, nothing of this step is kept: every stream that was decoding or was
+        started in this step goes back to the start of its segment (slots reset), and the next step() re-runs them on the
+        launch-per-phase paths the library has switched to.  Greedy decoding repeats the tokens, so the audio continues where it
+        stopped; with top_k > 1 the re-run draws with new per-call seeds -- the groups already emitted are skipped, what follows
+        comes from a different token sequence (an audible splice is possible)."""
+        self._popped = []
+        try:
+            return self._step()
+        except GenvcHipError as e:
+            if "timed out" not in str(e):          # (a full KV cache, ... : not recoverable by repeating the work)
+                raise
+            self._recover()
+            return {}
+
+    def _recover(self):
+        self.recoveries += 1
+        redo = []
+        for s in self.sessions.values():
+            if s.decoding:
+                self._requeue(s)
+                redo.append(s)
+        for s in self._popped:                     # started in the failed step, not yet marked decoding: put the segment back
+            if s not in redo and not s.decoding and s.current is not None and (not s.queue or s.queue[0] is not s.current[0]):
+                seg, past = s.current
+                s.queue.insert(0, seg)
+                s.past = past
+                s.prefilled = False
+                redo.append(s)
+        if redo:
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.eng.reset(torch.tensor([s.slot for s in redo], device=self.m.device, dtype=torch.int32))
+
+    def _step(self):
         m, eng, dev = self.m, self.eng, self.m.device
         out = {}
         # 1. segments that can start: batch by (segment length, cached or not)
@@ -127,6 +165,7 @@ class StreamSessions:
             ss = [self.sessions[i] for i in sids]
             for s in ss:
                 s.current = (s.queue[0], s.past)
+            self._popped.extend(ss)
             wav = torch.cat([s.queue.pop(0) for s in ss], 0)
             feat = self.segment_features(ss, wav)
             codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
@@ -161,19 +200,11 @@ class StreamSessions:
         self.calls += 1
         eng.generate(slots, ids, ids_len, fin, self.params, 0, n, toks, lats, max_keys=W - 8)
         th = toks.cpu()                                           # (synchronises: the steps above have run)
-        try:
-            eng.health()
-        except GenvcHipError as e:
-            if "timed out" not in str(e):          # (a full KV cache, ... : not recoverable by repeating the work)
-                raise
-            # a hand-off of the one-launch step timed out (not all workgroups resident, e.g. another context on the GPU): these tokens
-            # and latents are garbage and so are the K/V rows the steps appended.  Nothing of this call is kept or vocoded; the library
-            # has switched the context to the launch-per-phase paths, on which the affected segments are decoded again from their start
-            self.recoveries += 1
-            for _, s in act:
-                self._requeue(s)
-            eng.reset(slots)
-            return out
+        # a hand-off of the one-launch step that timed out (not all workgroups resident, e.g. another context on the GPU) raises here:
+        # these tokens and latents are garbage and so are the K/V rows the steps appended.  Nothing of this call is kept or vocoded
+        # (step() catches it); the library has switched the context to the launch-per-phase paths, on which the affected segments are
+        # decoded again from their start
+        eng.health()
         self.ids[idx, :W] = ids
         self.ids_len[idx] = ids_len
         self.finished[idx] = fin

@@ -184,6 +184,18 @@ long long gvc_gpt_rows_step_launches(gvc_gpt* ctx);
  * dropped, hand-off buffers re-initialised): the context stays usable, the caller resets the affected slots and repeats the work.
  * Also reports a full KV cache / mel position table (see gvc_gpt_reset_slots).  GVC_OK otherwise. */
 int gvc_gpt_health(gvc_gpt* ctx);
+/* Warm-up (reference: the user's own warm-up conversions, /root/reference/infer.py:27-30; SURVEY.md 8(b)(iii): no hidden
+ * synchronisation or allocation after create).  Does, for a generation over B streams that reaches max_keys cached positions
+ * (0: up to max_seq) with this top_k, everything the first data-path call of that shape would otherwise do itself: the one-launch
+ * steps' hand-off buffers, packed weight copy, XCD-topology probe and LDS opt-in, and the capture of the step graphs (eight steps /
+ * one step).  Synchronous; call it after the weights are bound, once per (B, context class, greedy or sampled) a deployment uses.
+ * Afterwards gvc_gpt_generate / gvc_gpt_decode_step / gvc_gpt_prefill_cached calls of that shape do no hipMalloc, no
+ * hipDeviceSynchronize and no graph capture. */
+int gvc_gpt_warmup(gvc_gpt* ctx, int32_t B, int32_t max_keys, int32_t top_k);
+/* Diagnostic: allocations / device-wide synchronisations / graph captures this context has done INSIDE data-path calls (first use
+ * of a path that gvc_gpt_warmup had not prepared; a rebind after the weight pack was built; the fallback after a hand-off
+ * time-out).  gvc_gpt_warmup's own work does not count.  Tests assert it stays put across warmed-up calls. */
+long long gvc_gpt_lazy_inits(gvc_gpt* ctx);
 
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head

@@ -384,3 +384,123 @@ def test_convert_offline_rolling_matches_waves():
     convert_offline(c, srcs, ref, seg_len=6.0, micro_batch=2, rolling=True)
     assert not c.gpt.rolling_calls and c.gpt.group_calls
     _StubModel.config.top_k = 1
+
+
+class _ToyEngine:
+    """CPU stand-in for GptEngine behind the REAL GPT.generate / GPT.generate_rolling host loops: a deterministic toy language model
+    whose next token depends on the slot's prefix AND on the whole id history of the row (what repetition_penalty reads), with
+    per-slot state as the library keeps it.  Any mix-up of slots, histories, budgets or retirement order changes the ids."""
+    STOP = 1025
+
+    def __init__(self, stop_every=7):
+        self.sig = {}                      # slot -> prefix signature
+        self.stop_every = stop_every
+        self.calls = []                    # rows per generate call
+
+    def prefix_embeddings(self, cond, codes):
+        B, Tc = codes.shape
+        p = torch.zeros(B, cond.shape[1] + Tc + 2, 1)
+        p[:, 0, 0] = (codes.long().sum(1) * 31 + (cond.sum((1, 2)) * 100).long() + Tc).float()
+        return p
+
+    def prefill(self, slots, prefix, want_outputs=False, n_cached=0):
+        for b, s in enumerate(slots.tolist()):
+            self.sig[s] = int(prefix[b, 0, 0])
+
+    def generate(self, slots, ids, ids_len, fin, params, i0, n, toks, lats, max_keys=0):
+        self.calls.append(int(slots.shape[0]))
+        for b, s in enumerate(slots.tolist()):
+            for i in range(n):
+                L = int(ids_len[b])
+                if int(fin[b]):
+                    t = self.STOP
+                else:
+                    h = (self.sig[s] * 131 + int((ids[b, :L].long() * torch.arange(1, L + 1)).sum())) % 100003
+                    t = self.STOP if h % self.stop_every == 0 else h % 1024
+                    if t == self.STOP:
+                        fin[b] = 1
+                ids[b, L] = t
+                ids_len[b] = L + 1
+                toks[b, i0 + i] = t
+
+    def health(self):
+        pass
+
+
+def _toy_gpt(max_slots, stop_every=7):
+    from genvc_amd.layers.gpt import GPT
+    g = GPT(layers=1, model_dim=64, heads=1)
+    g.engine = _ToyEngine(stop_every)
+    g.max_slots = max_slots
+    return g
+
+
+def test_generate_rolling_retires_rows_one_by_one_and_matches_generate():
+    """GPT.generate_rolling (the offline leg's decode driver) over a fake engine: jobs of unequal size and prefix length, rows that stop
+    at ragged steps (per-row retirement, /root/reference/layers/stream_generator.py:861-874), a job that runs out of budget, slots
+    reused out of order with repetition_penalty > 1 (the id history of a reused slot must start clean), max_rows below the slot
+    count -- every job must get exactly what generate() gives it alone."""
+    torch.manual_seed(0)
+    sizes = [(5, 9), (3, 4), (8, 13), (1, 6), (6, 9), (2, 20), (7, 5), (4, 11)]
+    jobs = [(torch.rand(b, 32, 2), torch.randint(0, 256, (b, tc))) for b, tc in sizes]
+    budgets = [40, 40, 12, 40, 25, 40, 40, 9]
+    kw = dict(top_k=1, top_p=0.85, temperature=0.85, repetition_penalty=2.0, do_sample=True, num_beams=1)
+    solo = []
+    for (c, t), bud in zip(jobs, budgets):
+        g = _toy_gpt(8)
+        solo.append(g.generate(c, t, group=4, max_new_tokens=bud, **kw))
+    ends = [int(((o == 1025).long().argmax(1) + (o != 1025).all(1).long() * o.shape[1]).max()) for o in solo]
+    assert len(set(ends)) >= 4, ends                         # the jobs really end ragged
+    for max_slots, max_rows, group in ((16, None, 4), (16, 9, 3), (8, None, 16), (12, None, 1)):
+        g = _toy_gpt(max_slots)
+        g.rolling_stats = {}
+        out = g.generate_rolling(jobs, group=group, max_rows=max_rows, max_new_tokens=budgets, **kw)
+        for i, (o, ref) in enumerate(zip(out, solo)):
+            assert torch.equal(o, ref), f"max_slots {max_slots} max_rows {max_rows} group {group}: job {i} differs from generate()"
+        cap = min(max_slots, max_rows or max_slots)
+        assert max(g.engine.calls) <= cap
+        st = g.rolling_stats
+        assert st["row_steps_live"] <= st["row_steps_issued"]
+        if group == 1:                                       # a host look after every step: a stopped row never takes another step
+            assert st["row_steps_live"] == st["row_steps_issued"]
+    # a job wider than the streams in flight is refused loudly
+    with pytest.raises(ValueError):
+        _toy_gpt(4).generate_rolling(jobs, max_new_tokens=8, **kw)
+
+
+def _gather8_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from genvc_amd.parallel_offline import convert_offline
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    srcs = [torch.rand(1, 160000) for _ in range(64)]
+    ref = torch.rand(1, 72000)
+    toks = convert_offline(_StubModel(), srcs, ref, seg_len=6.0, micro_batch=8, rank=rank, world=world, rolling=True,
+                           tokens_per_second=2.0, max_new_tokens=12)
+    if rank == 0:
+        q.put(toks.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_convert_offline_world8_equals_world1_for_64_utterances():
+    """BASELINE configs[2]'s sharding at the size the driver runs it: 64 utterances, micro-batch 8, EIGHT ranks (gloo on CPU) -- the
+    all_gather result on rank 0 must equal the single-process result, utterance by utterance
+    (partitioning: /root/reference/inference/inference_utils.py:43-77; plan: genvc_amd/parallel_offline.py)."""
+    import torch.multiprocessing as mp
+    from genvc_amd.parallel_offline import convert_offline
+    torch.manual_seed(5)
+    srcs = [torch.rand(1, 160000) for _ in range(64)]
+    ref = torch.rand(1, 72000)
+    one = convert_offline(_StubModel(), srcs, ref, seg_len=6.0, micro_batch=8, rolling=True, tokens_per_second=2.0, max_new_tokens=12).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_gather8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape == one.shape and np.array_equal(got, one)
