@@ -923,7 +923,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         return GVC_OK;
     }
     if (getenv("GVC_PERSIST_STAMPS")) {        // diagnostics only: a failed allocation just leaves the stamps off
-        const size_t nb = (size_t)(20 * (L + 2) + 4 * 5 * kPG) * sizeof(unsigned long long);
+        const size_t nb = (size_t)(40 * (L + 2) + 8 * 5 * kPG) * sizeof(unsigned long long);
         if (hipMalloc((void**)&c->r_dbg, nb) != hipSuccess || hipMemset(c->r_dbg, 0, nb) != hipSuccess) {
             if (c->r_dbg) (void)hipFree(c->r_dbg);
             c->r_dbg = nullptr;
@@ -1571,7 +1571,7 @@ extern "C" int gvc_gpt_health(gvc_gpt* c) { return check_ready(c); }
 extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, int32_t max_launches) {
     if (c && c->r_dbg && max_launches == -2) {    // stamps of the last one-launch rows step: workgroup 0, [(layer * 5 + phase) * 4 + k]
         (void)hipDeviceSynchronize();
-        const int n = 20 * (c->dm.n_layer + 2) + 4 * 5 * kPG;
+        const int n = 40 * (c->dm.n_layer + 2) + 8 * 5 * kPG;
         (void)hipMemcpy(host_out, c->r_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         return n;
     }

@@ -347,16 +347,34 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
     }
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(A.bufs, (unsigned)rows_buf_bytes());
     const float scale = 1.0f / sqrtf((float)hd);
-    // stamps (GVC_PERSIST_STAMPS): workgroup 0, every layer: [(l * 5 + p) * 4 + k], k = 0 input gathered, 1 output published, 2 extra;
-    // every workgroup at layer 2: [20 (L + 2) + (wg * 5 + p) * 4 + k]
+    // stamps (GVC_PERSIST_STAMPS; wave 0, lane 0): workgroup 0, every layer: [(l * 5 + p) * 8 + k]; every workgroup at layer 2:
+    // [40 (L + 2) + (wg * 5 + p) * 8 + k].  k = 0 input gathered, 1 output published, 2 LayerNorm statistics merged (B: own gathers
+    // done, before the barrier), 3 weight fills waited for, 4 MFMA loop (B: score loop) done, 5 partials written to LDS, 6 barrier
+    // passed, 7 final values ready (before the publish)
     const bool stamp0 = A.dbg && wave == 0 && c.lane == 0;
-    const int sbase2 = 20 * (A.n_layer + 2);
+    const int sbase2 = 40 * (A.n_layer + 2);
     auto stamp_at = [&](int l, int p, int k) {
-        if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 4 + k] = wall_clock64();
-        if (stamp0 && l == 2) A.dbg[sbase2 + (wg * 5 + p) * 4 + k] = wall_clock64();
+        if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 8 + k] = wall_clock64();
+        if (stamp0 && l == 2) A.dbg[sbase2 + (wg * 5 + p) * 8 + k] = wall_clock64();
     };
     unsigned fs = 0;
     auto phase_done = [&]() { if (lane == 0) lds_st(ctl + kCtlDone + wave, fs); };
+    // per-row metadata does not change during a launch: read once, not once per layer behind two dependent loads
+    // (phase A's cache append: the row of lane `lane`; phase B: the row of this workgroup)
+    int a_slot = 0, a_pos = 0;
+    if (c.lane < A.rows) {
+        const int bs = c.lane / A.T;
+        a_slot = A.slots[bs];
+        a_pos = (A.base_len ? A.base_len[a_slot] : 0) + (c.lane - bs * A.T);
+    }
+    int b_slot = 0, b_base = 0;
+    {
+        const int nb = wg / (nch * SH);
+        if (nb < A.rows) {
+            b_slot = __builtin_amdgcn_readfirstlane(A.slots[nb / A.T]);
+            b_base = __builtin_amdgcn_readfirstlane(A.base_len ? A.base_len[b_slot] : 0);
+        }
+    }
 
     for (int l = 0; l < A.n_layer; ++l) {
         const RowsLayer* Lp = A.layers + l;
@@ -409,6 +427,16 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                         if (i == sq - s0) *reinterpret_cast<float4*>(resid + n * 4) = xv[i];
                 }
             }
+            // the first step's weights and gains are requested from LDS BEFORE the LayerNorm statistics merge (a barrier and two LDS round
+            // trips): the fills are there long before (the loader runs ahead), so their read latency hides behind the merge
+            wait_fill(c, fs + 2);
+            stamp_at(l, 0, 3);
+            const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
+            const float* gb = gbs + (wave * 64 + kk) * 4;
+            float4 wc[3], wn[3], gc, bc, gn, bn;
+#pragma unroll
+            for (int rg = 0; rg < 3; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+            gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
             // LayerNorm: per-wave (mean, M2) of the wave's K-slice, merged over the eight waves (Chan et al.)
             float mean_, rstd_;
             {
@@ -440,19 +468,13 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 rstd_ = 1.0f / sqrtf(var + 1e-5f);
                 mean_ = mean;
             }
+            stamp_at(l, 0, 2);
             pf32x4 acc[3];
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
-            wait_fill(c, fs + 2);
             {
                 // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
                 // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
-                const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
-                const float* gb = gbs + (wave * 64 + kk) * 4;
-                float4 wc[3], wn[3], gc, bc, gn, bn;
-#pragma unroll
-                for (int rg = 0; rg < 3; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
-                gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
                     if (i + 1 < NSX) {
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     gc = gn; bc = bn;
                 }
             }
-            stamp_at(l, 0, 2);
+            stamp_at(l, 0, 4);
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg) {
                 const float4 r = make_float4(kk_sum<R>(acc[rg][0]), kk_sum<R>(acc[rg][1]), kk_sum<R>(acc[rg][2]), kk_sum<R>(acc[rg][3]));
@@ -484,8 +506,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             }
             fs += 3;
             phase_done();
+            stamp_at(l, 0, 5);
             cbar(c);
-            stamp_at(l, 0, 3);
+            stamp_at(l, 0, 6);
             if (wave < 3 && lane < R) {                       // wave rg finishes row group rg for row `lane`
                 const int rg = wave, rn = lane;
                 float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + rg) * kRMaxRows + rn) * 4);
@@ -500,13 +523,14 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 if (KVB && col >= D) {                        // a bf16 cache: k and v are rounded where they enter it, and this step's
                     s.x = bf16_round(s.x); s.y = bf16_round(s.y); s.z = bf16_round(s.z); s.w = bf16_round(s.w);      // attention reads the same values
                 }
+                stamp_at(l, 0, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's poison of the previous layer has landed
                 const int eo = (kRoffQKV + rn * 3 * D + col) * 4;
                 rpublish(brs, pc + eo, po + eo, s);
+                stamp_at(l, 0, 1);
                 if (col >= D && rn < A.rows) {                // append k / v of this row to its stream's cache (read by later launches)
                     const int which = col / D, ci = col - which * D, h = ci / hd, j = ci - h * hd;
-                    const int bstream = rn / A.T, t = rn - bstream * A.T, slot = A.slots[bstream];
-                    const int pos = (A.base_len ? A.base_len[slot] : 0) + t;
+                    const int slot = a_slot, pos = a_pos;
                     if (pos < A.max_seq) {
                         float* cache = which == 1 ? Lp->kcache : Lp->vcache;
                         const size_t e = (((size_t)slot * H + h) * A.max_seq + pos) * hd + j;
@@ -519,7 +543,6 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     } else *A.err = 950;                      // KV cache full: GVC_ERR_STATE on the host's next call
                 }
             }
-            stamp_at(l, 0, 1);
         }
         // =================== B: attention of one (row, head, key chunk) per workgroup ===================
         if (wg < R * SH * nch) {
@@ -528,8 +551,8 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int sub = lane / lpk, hreal = h * (HD / hd) + sub, dl = (lane - sub * lpk) * 4;    // this lane's real head, its dims inside it
             const bool active = n < A.rows;
             const int bstream = active ? n / A.T : 0, t = active ? n - bstream * A.T : 0, r0 = bstream * A.T;
-            const int slot = A.slots[bstream];
-            const int base = A.base_len ? A.base_len[slot] : 0;
+            const int slot = b_slot;
+            const int base = b_base;
             const int k0 = active ? (int)(((long long)base * ch) / nch) : 0, k1 = active ? (int)(((long long)base * (ch + 1)) / nch) : 0;
             const bool last = active && ch == nch - 1;           // the new rows [r0, n] of this very step belong to the last chunk
             constexpr int ESZ = KVB ? 2 : 4;                     // bytes per cache element
@@ -563,30 +586,41 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 }
             };
             load_pass(k0);                                       // requested ahead of the seam
-            // q of (row, super-head): 256 floats, one 16-byte load per lane of wave 0
-            if (wave == 0 && active) {
-                pu32x4 qv[1];
-                rgather<1>(c, brs, pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16, 0, qv, 200 + l);
-                *reinterpret_cast<float4*>(ascr + lane * 4) = as_f4(qv[0]);
-            }
-            // new rows r0 + j <= n of this very step: k and v from the hand-off buffer; row j belongs to wave (j + 1) % 8, so a decode
-            // step's single new key is gathered beside q, not behind it
+            // q of (row, super-head): 256 floats = one 16-byte piece per lane, gathered by EVERY wave for itself (1 KiB per wave from L2
+            // instead of wave 0 -> LDS -> barrier: one barrier less on the critical path of the phase).
+            // New rows r0 + j <= n of this very step: k and v from the hand-off buffer; row j belongs to wave (j + 1) % 8.  A decode
+            // step's single new key (j = 0: the row itself) comes in the same round trip as q: q | k | v are D floats apart.
+            float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 kn[2], vn[2];
             bool has_new[2] = {false, false};
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int j = ((wave + kPCW - 1) & (kPCW - 1)) + jj * kPCW;
-                kn[jj] = vn[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (last && j <= t) {
-                    has_new[jj] = true;
+            kn[0] = vn[0] = kn[1] = vn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int j0 = (wave + kPCW - 1) & (kPCW - 1);
+            const int qoff = pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16;
+            if (last && j0 <= t && r0 + j0 == n) {               // (wave-uniform)
+                has_new[0] = true;
+                pu32x4 qkv[3];
+                rgather<3>(c, brs, qoff, D * 4, qkv, 200 + l, true);
+                q4 = as_f4(qkv[0]); kn[0] = as_f4(qkv[1]); vn[0] = as_f4(qkv[2]);
+            } else {
+                if (active) {
+                    pu32x4 qv[1];
+                    rgather<1>(c, brs, qoff, 0, qv, 200 + l);
+                    q4 = as_f4(qv[0]);
+                }
+                if (last && j0 <= t) {
+                    has_new[0] = true;
                     pu32x4 kv[2];
-                    rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l);
-                    kn[jj] = as_f4(kv[0]); vn[jj] = as_f4(kv[1]);
+                    rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j0) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l, true);
+                    kn[0] = as_f4(kv[0]); vn[0] = as_f4(kv[1]);
                 }
             }
-            cbar(c);
+            if (last && j0 + kPCW <= t) {
+                has_new[1] = true;
+                pu32x4 kv[2];
+                rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j0 + kPCW) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l, true);
+                kn[1] = as_f4(kv[0]); vn[1] = as_f4(kv[1]);
+            }
             stamp_at(l, 1, 0);
-            const float4 q4 = *reinterpret_cast<const float4*>(ascr + lane * 4);
             float m = -INFINITY, lsum = 0.f;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             // online softmax over a batch of NB scores (-inf: no key): one rescale per batch
@@ -623,12 +657,15 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 for (int jj = 0; jj < 2; ++jj) sc[jj] = has_new[jj] ? group_sum(dot4(q4, kn[jj]), lpk) * scale : -INFINITY;
                 fold(sc, vn, std::integral_constant<int, 2>());
             }
+            stamp_at(l, 1, 4);
             float* m_s = ascr + 256;                             // [kPCW][4 real heads of the super-head]
             float* l_s = m_s + kPCW * 4;
             float* o_s = l_s + kPCW * 4;
             if (dl == 0) { m_s[wave * 4 + sub] = m; l_s[wave * 4 + sub] = lsum; }
             *reinterpret_cast<float4*>(o_s + wave * 256 + lane * 4) = o;
+            stamp_at(l, 1, 5);
             cbar(c);
+            stamp_at(l, 1, 6);
             if (wave == 0) {
                 float M = -INFINITY;
 #pragma unroll
@@ -647,6 +684,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     const float inv = 1.0f / Lt;
                     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
                 } else { M = -1e30f; Lt = 0.f; }                           // a chunk without keys (or a padding row): weight 0
+                stamp_at(l, 1, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 // frag position of (row n, k-quad h * 64 + lane) in C's B-operand order
                 const int q = h * 64 + lane;
@@ -735,6 +773,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             stamp_at(l, 2, 0);
             pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             wait_fill(c, fs);
+            stamp_at(l, 2, 3);
             {
                 const char* wbase = ring + (size_t)(fs & rmask) * kPSlot + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
                 float4 wc = ldw4<WB>(wbase), wn;
@@ -749,6 +788,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     wc = wn;
                 }
             }
+            stamp_at(l, 2, 4);
             {
                 const float4 r = make_float4(kk_sum<R>(acc0[0] + acc1[0]), kk_sum<R>(acc0[1] + acc1[1]), kk_sum<R>(acc0[2] + acc1[2]),
                                              kk_sum<R>(acc0[3] + acc1[3]));
@@ -756,7 +796,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             }
             fs += 1;
             phase_done();
+            stamp_at(l, 2, 5);
             cbar(c);
+            stamp_at(l, 2, 6);
             if (wave == 0 && lane < R) {
                 const int rn = lane;
                 float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + 0) * kRMaxRows + rn) * 4);
@@ -769,6 +811,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 const float4 xr = *reinterpret_cast<const float4*>(resid + rn * 4);
                 s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
                 *reinterpret_cast<float4*>(resid + rn * 4) = s;           // x': the residual of phase E
+                stamp_at(l, 2, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int fl = (wg / KK) * 64 + (((rn >> 2) * KK + (wg % KK)) * 4 + (rn & 3));
                 const int eo = kRoffX0 * 4 + fl * 16;
@@ -802,6 +845,15 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                         if (i == sq - s0) *reinterpret_cast<float4*>(resid2 + (ge * kRMaxRows + n) * 4) = xv[i];
                 }
             }
+            // (first step's weights and gains requested ahead of the LayerNorm merge, as in phase A)
+            wait_fill(c, fs + 3);
+            stamp_at(l, 3, 3);
+            const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
+            const float* gb = gbs + (wave * 64 + kk) * 4;
+            float4 wc[4], wn[4], gc, bc, gn, bn;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
+            gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
             float mean_, rstd_;
             {
                 float s = 0.f;
@@ -832,21 +884,13 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 rstd_ = 1.0f / sqrtf(var + 1e-5f);
                 mean_ = mean;
             }
-                        pf32x4 acc[4];
+            pf32x4 acc[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
             stamp_at(l, 3, 2);
-            wait_fill(c, fs + 3);
-            stamp_at(l, 3, 3);
             {
                 // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
                 // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
-                const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
-                const float* gb = gbs + (wave * 64 + kk) * 4;
-                float4 wc[4], wn[4], gc, bc, gn, bn;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
-                gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) {
                     if (i + 1 < NSX) {
@@ -870,6 +914,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     gc = gn; bc = bn;
                 }
             }
+            stamp_at(l, 3, 4);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float4 r = make_float4(kk_sum<R>(acc[rg][0]), kk_sum<R>(acc[rg][1]), kk_sum<R>(acc[rg][2]), kk_sum<R>(acc[rg][3]));
@@ -877,7 +922,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             }
             fs += 4;
             phase_done();
+            stamp_at(l, 3, 5);
             cbar(c);
+            stamp_at(l, 3, 6);
             if (wave < 4 && lane < R) {
                 const int rg = wave, rn = lane;
                 float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + rg) * kRMaxRows + rn) * 4);
@@ -888,6 +935,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 }
                 const float4 bi = bpre;
                 s.x = gelu_new(s.x + bi.x); s.y = gelu_new(s.y + bi.y); s.z = gelu_new(s.z + bi.z); s.w = gelu_new(s.w + bi.w);
+                stamp_at(l, 3, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int q = wg * 4 + rg;                   // k-quad of the hidden units [16 wg + 4 rg, +4)
                 const int fl = (q / KK) * 64 + (((rn >> 2) * KK + (q % KK)) * 4 + (rn & 3));
@@ -914,6 +962,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 // group ge lies in fills fs + 2 ge, fs + 2 ge + 1 (32 KiB of fp32); the wave's NSE steps sit inside one fill
                 const unsigned boff = (unsigned)sl * STEPB;
                 wait_fill(c, fs + 2 + (boff >> 14));
+                stamp_at(l, 4, 3);
                 const char* wb0 = ring + (((boff & 16383u) + (lane & LMASK) * 16) >> WB);
                 const char* w0 = wb0 + (size_t)((fs + (boff >> 14)) & rmask) * kPSlot;
                 const char* w1 = wb0 + (size_t)((fs + 2 + (boff >> 14)) & rmask) * kPSlot;
@@ -934,6 +983,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     wc0 = wn0; wc1 = wn1;
                 }
             }
+            stamp_at(l, 4, 4);
 #pragma unroll
             for (int ge = 0; ge < 2; ++ge) {
                 const float4 r = make_float4(kk_sum<R>(acc[ge][0]), kk_sum<R>(acc[ge][1]), kk_sum<R>(acc[ge][2]), kk_sum<R>(acc[ge][3]));
@@ -941,7 +991,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             }
             fs += 4;
             phase_done();
+            stamp_at(l, 4, 5);
             cbar(c);
+            stamp_at(l, 4, 6);
             if (wave < 2 && lane < R) {
                 const int ge = wave, rn = lane;
                 float4 s = *reinterpret_cast<const float4*>(red + ((0 * 4 + ge) * kRMaxRows + rn) * 4);
@@ -955,6 +1007,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     const float4 xr = *reinterpret_cast<const float4*>(resid2 + (ge * kRMaxRows + rn) * 4);
                     s.x = xr.x + (s.x + bi.x); s.y = xr.y + (s.y + bi.y); s.z = xr.z + (s.z + bi.z); s.w = xr.w + (s.w + bi.w);
                 }
+                stamp_at(l, 4, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int q = cb * 2 + ge;
                 const int fl = (q / KK) * 64 + (((rn >> 2) * KK + (q % KK)) * 4 + (rn & 3));

@@ -132,7 +132,7 @@ def test_rolling_decode_retires_rows_at_ragged_eos_and_keeps_the_step_full():
     gj = [(c.to(DEV), t.to(DEV)) for c, t in jobs]
     g.rolling_stats = {}
     out = g.generate_rolling(gj, group=2, max_new_tokens=ROLL_BUDGET, **GREEDY_KW)
-    assert g.engine.decode_variant() == 5
+    assert g.engine.decode_variant() in (3, 5)        # (the one-launch steps: rows step, or the one-stream step when a single row is left)
     for i, (o, r) in enumerate(zip(out, ref)):
         assert o.shape == r.shape and torch.equal(o.cpu(), r), f"job {i}: ids differ from the oracle's loop"
     st = g.rolling_stats
