@@ -274,6 +274,7 @@ struct gvc_gpt {
     RowsLayer* r_layers = nullptr;
     float* r_wpack = nullptr;         // packed weights [layer][256][192 KiB]
     float* r_bufs = nullptr;          // hand-off buffers, two parities
+    float* r_lnfold = nullptr;        // per layer: S[3d] | C[3d] of LN1 -> c_attn and S[4d] | C[4d] of LN2 -> c_fc (k_rows_ln_fold)
     unsigned long long* r_dbg = nullptr;   // GVC_PERSIST_STAMPS
     std::vector<char> r_dirty;         // per layer: a matrix was re-bound after the pack was built (gvc_gpt_bind_weight) -> repack before use
     size_t r_lds = 0;
@@ -409,7 +410,7 @@ extern "C" int gvc_gpt_destroy(gvc_gpt* c) {
     if (c->xalt) hipFree(c->xalt);
     if (c->seam_err_host) hipHostFree(c->seam_err_host);
     for (void* p : {(void*)c->p_layers, (void*)c->p_gran, (void*)c->p_epoch, (void*)c->p_dbg, (void*)c->r_layers, (void*)c->r_wpack,
-                    (void*)c->r_bufs, (void*)c->r_dbg})
+                    (void*)c->r_bufs, (void*)c->r_dbg, (void*)c->r_lnfold})
         if (p) hipFree(p);
     for (void* p : {(void*)c->wbase, (void*)c->wfm, (void*)c->wh, (void*)c->kv, (void*)c->x, (void*)c->a, (void*)c->q, (void*)c->h,
                     (void*)c->part, (void*)c->work, (void*)c->logits, (void*)c->latent, (void*)c->slot_logits, (void*)c->slot_latent, (void*)c->state, (void*)c->x2, (void*)c->part2,
@@ -476,16 +477,16 @@ extern "C" int gvc_gpt_bind_weight(gvc_gpt* c, const char* name, const float* sr
         const std::string rest = n.substr(dot + 1);
         GVC_REQUIRE(li >= 0 && li < c->dm.n_layer, GVC_ERR_ARG, "%s: layer out of range", name);
         GptLayer& ly = c->layers[li];
-        if (rest == "ln_1.weight") rc = copy_w(ly.ln1_w, src, numel, d, name, s);
-        else if (rest == "ln_1.bias") rc = copy_w(ly.ln1_b, src, numel, d, name, s);
+        if (rest == "ln_1.weight") { rc = copy_w(ly.ln1_w, src, numel, d, name, s); mark_rows_pack_dirty(c, li); }   // (the rows step folds the
+        else if (rest == "ln_1.bias") { rc = copy_w(ly.ln1_b, src, numel, d, name, s); mark_rows_pack_dirty(c, li); }    //  LayerNorm into per-row constants)
         else if (rest == "attn.c_attn.weight") { rc = transpose_w(ly.qkv_w, src, numel, d, 3 * d, name, s, ly.qkv_f, ly.qkv_h); mark_rows_pack_dirty(c, li); }
-        else if (rest == "attn.c_attn.bias") rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s);
+        else if (rest == "attn.c_attn.bias") { rc = copy_w(ly.qkv_b, src, numel, 3 * d, name, s); mark_rows_pack_dirty(c, li); }
         else if (rest == "attn.c_proj.weight") { rc = transpose_w(ly.proj_w, src, numel, d, d, name, s, ly.proj_f, ly.proj_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "attn.c_proj.bias") rc = copy_w(ly.proj_b, src, numel, d, name, s);
-        else if (rest == "ln_2.weight") rc = copy_w(ly.ln2_w, src, numel, d, name, s);
-        else if (rest == "ln_2.bias") rc = copy_w(ly.ln2_b, src, numel, d, name, s);
+        else if (rest == "ln_2.weight") { rc = copy_w(ly.ln2_w, src, numel, d, name, s); mark_rows_pack_dirty(c, li); }
+        else if (rest == "ln_2.bias") { rc = copy_w(ly.ln2_b, src, numel, d, name, s); mark_rows_pack_dirty(c, li); }
         else if (rest == "mlp.c_fc.weight") { rc = transpose_w(ly.fc_w, src, numel, d, 4 * d, name, s, ly.fc_f, ly.fc_h); mark_rows_pack_dirty(c, li); }
-        else if (rest == "mlp.c_fc.bias") rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s);
+        else if (rest == "mlp.c_fc.bias") { rc = copy_w(ly.fc_b, src, numel, 4 * d, name, s); mark_rows_pack_dirty(c, li); }
         else if (rest == "mlp.c_proj.weight") { rc = transpose_w(ly.p2_w, src, numel, 4 * d, d, name, s, ly.p2_f, ly.p2_h); mark_rows_pack_dirty(c, li); }
         else if (rest == "mlp.c_proj.bias") rc = copy_w(ly.p2_b, src, numel, d, name, s);
         else known = false;   // attn.bias / attn.masked_bias buffers of 4.33-era checkpoints
@@ -857,7 +858,7 @@ static const void* rows_kernel(const gvc_gpt* c, int R) {
 }
 
 static void rows_persist_release(gvc_gpt* c) {
-    for (void** p : {(void**)&c->r_layers, (void**)&c->r_wpack, (void**)&c->r_bufs, (void**)&c->r_dbg})
+    for (void** p : {(void**)&c->r_layers, (void**)&c->r_wpack, (void**)&c->r_bufs, (void**)&c->r_dbg, (void**)&c->r_lnfold})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     (void)hipGetLastError();
     c->r_ready = -1;
@@ -873,6 +874,13 @@ static void rows_pack_layer(gvc_gpt* c, int l) {
                                 (const float*)ly.fc_w, (const float*)ly.p2_w);
     else hipLaunchKernelGGL(k_pack_rows_weights<0>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
                             (const float*)ly.fc_w, (const float*)ly.p2_w);
+    // LayerNorm folded into per-output-row constants (persist_rows.h, phases A / D): S_r = sum_k W_rk g_k, C_r = sum_k W_rk b_k + bias_r
+    const int d = kRD;
+    float* f = c->r_lnfold + (size_t)l * 14 * d;
+    hipLaunchKernelGGL(k_rows_ln_fold, dim3(3 * d / 4), dim3(256), 0, 0, f, f + 3 * d, (const float*)ly.qkv_w, (const float*)ly.ln1_w,
+                       (const float*)ly.ln1_b, (const float*)ly.qkv_b, 3 * d, d);
+    hipLaunchKernelGGL(k_rows_ln_fold, dim3(4 * d / 4), dim3(256), 0, 0, f + 6 * d, f + 10 * d, (const float*)ly.fc_w, (const float*)ly.ln2_w,
+                       (const float*)ly.ln2_b, (const float*)ly.fc_b, 4 * d, d);
 }
 
 static int rows_persist_prepare(gvc_gpt* c) {
@@ -905,6 +913,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern[0], kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
         hipMalloc((void**)&c->r_wpack, (size_t)L * kPG * (kRWgLayerBytes >> wsh)) != hipSuccess ||
         hipMalloc((void**)&c->r_bufs, rows_buf_bytes()) != hipSuccess ||
+        hipMalloc((void**)&c->r_lnfold, (size_t)L * 14 * kRD * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->r_layers, L * sizeof(RowsLayer)) != hipSuccess) {
         rows_persist_release(c);
         return GVC_OK;
@@ -915,6 +924,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         RowsLayer& p = t[l];
         p.ln1_w = ly.ln1_w; p.ln1_b = ly.ln1_b; p.qkv_b = ly.qkv_b; p.proj_b = ly.proj_b; p.ln2_w = ly.ln2_w; p.ln2_b = ly.ln2_b;
         p.fc_b = ly.fc_b; p.p2_b = ly.p2_b; p.kcache = kv_layer(c, l, 0); p.vcache = kv_layer(c, l, 1);
+        p.lnS_a = c->r_lnfold + (size_t)l * 14 * kRD; p.lnC_a = p.lnS_a + 3 * kRD; p.lnS_d = p.lnS_a + 6 * kRD; p.lnC_d = p.lnS_a + 10 * kRD;
         rows_pack_layer(c, l);
     }
     if (hipGetLastError() != hipSuccess || hipMemcpy(c->r_layers, t.data(), L * sizeof(RowsLayer), hipMemcpyHostToDevice) != hipSuccess ||
@@ -947,6 +957,8 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     A.poll_all = poll_all;
     static const int rows_loader_depth = getenv("GVC_ROWS_LOADER_DEPTH") ? atoi(getenv("GVC_ROWS_LOADER_DEPTH")) : 2;
     A.loader_depth = rows_loader_depth;
+    static const int rows_opt = getenv("GVC_ROWS_OPT") ? atoi(getenv("GVC_ROWS_OPT")) : 1;
+    A.opt = rows_opt;
     // keys of a (row, head) over 2 / 4 workgroups: 8 rows from 80 / 160 cached positions (one 80-key pass per workgroup; 744 vs 766 us
     // per step at 48-112 keys, 815 vs 827 at 110-250), 16 rows from 128 / 288 (their chunk merge gathers 64 KB per chunk: 1068 vs 1104 us)
     A.split1 = c->r_split1 > 0 ? c->r_split1 : (rows <= 8 ? 80 : 128);

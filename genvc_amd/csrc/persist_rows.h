@@ -56,6 +56,9 @@ typedef float pf32x4 __attribute__((ext_vector_type(4)));
 struct RowsLayer {
     const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc_b, *p2_b;
     float *kcache, *vcache;         // this layer's [slot][head][max_seq][hd]
+    // LayerNorm folded into the projection that follows it (k_rows_ln_fold): LN(x) W^T + bias = rstd (sum_k W_rk g_k x_k - mean S_r) + C_r
+    const float *lnS_a, *lnC_a;     // [3d]: LN1 -> c_attn
+    const float *lnS_d, *lnC_d;     // [4d]: LN2 -> c_fc
 };
 
 struct RowsArgs {
@@ -76,6 +79,7 @@ struct RowsArgs {
     int split1, split2;             // cached positions from which the keys of a (row, head) take 2 / 4 workgroups
     int poll_all;                   // gathers of up to this many 16-byte pieces per lane re-request everything in every poll pass
     int loader_depth;               // LDS-DMA fills in flight per loader wave (1 or 2)
+    int opt;                        // A/B switches (GVC_ROWS_OPT, default 1): bit 0: every wave of phase B gathers q itself (else wave 0 -> LDS -> barrier)
     unsigned long long* dbg;
 };
 
@@ -104,6 +108,41 @@ __global__ void k_pack_rows_weights(float* dst, const float* qkv, const float* p
             reinterpret_cast<uint2*>(dst)[i] = h;
         } else reinterpret_cast<float4*>(dst)[i] = v;
     }
+}
+
+// S_r = sum_k W_rk g_k and C_r = sum_k W_rk b_k + bias_r of one LayerNorm -> projection pair (W row-per-output [N][K], the values the
+// rows step multiplies with: bf16-rounded in a bf16-weights context); double accumulation, one wave per output row
+__global__ void k_rows_ln_fold(float* S, float* Cc, const float* W, const float* g, const float* b, const float* bias, int N, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    double s = 0.0, c = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double w = (double)W[(size_t)row * K + k];
+        s += w * (double)g[k];
+        c += w * (double)b[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); c += __shfl_xor(c, o); }
+    if (lane == 0) { S[row] = (float)s; Cc[row] = (float)(c + (double)bias[row]); }
+}
+
+// LayerNorm statistics of row rn over the whole model dim from the eight waves' (mean, M2) partials in LDS (Chan et al.); cnt =
+// elements per partial
+__device__ __forceinline__ void ln_merge(const float* stat, int rn, float cnt, float inv_d, float& mean, float& rstd) {
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < kPCW; ++w) m += stat[w * 16 + rn];
+    m *= 1.0f / (float)kPCW;
+    float M2 = 0.f, dv = 0.f;
+#pragma unroll
+    for (int w = 0; w < kPCW; ++w) {
+        const float dm = stat[w * 16 + rn] - m;
+        M2 += stat[kPCW * 16 + w * 16 + rn];
+        dv += dm * dm;
+    }
+    const float var = (M2 + dv * cnt) * inv_d;
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+    mean = m;
 }
 
 // four consecutive weights of one row from the ring: 16 bytes of fp32, or 8 bytes of bf16 widened in registers
@@ -386,10 +425,13 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
             const int s0 = wave * NSX;
             float4 xv[NSX];
-            const float4 bpre = *reinterpret_cast<const float4*>(Lp->qkv_b + wg * 12 + (wave < 3 ? wave : 0) * 4);   // (requested ahead of the seam)
-            // LayerNorm gains / biases of the wave's 32 k-quads -> LDS (read back one step at a time next to the MFMAs)
-            *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) =
-                *reinterpret_cast<const float4*>((lane < 32 ? Lp->ln1_w : Lp->ln1_b) + (s0 * KK + (lane & 31)) * 4);
+            // LayerNorm folded into the projection: LN1(x) W^T + bias = rstd (sum_k W_rk g_k x_k - mean S_r) + C_r.  The MFMAs run on g x
+            // while the waves' (mean, M2) partials travel to LDS beside the partial sums: ONE barrier per phase, no LayerNorm merge in
+            // front of the arithmetic.  S_r, C_r of the final lanes' four columns (requested ahead of the seam):
+            const float4 Spre = *reinterpret_cast<const float4*>(Lp->lnS_a + wg * 12 + (wave < 3 ? wave : 0) * 4);
+            const float4 Cpre = *reinterpret_cast<const float4*>(Lp->lnC_a + wg * 12 + (wave < 3 ? wave : 0) * 4);
+            // LayerNorm gains of the wave's 32 k-quads -> LDS (read back one step at a time next to the MFMAs)
+            if (lane < 32) *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) = *reinterpret_cast<const float4*>(Lp->ln1_w + (s0 * KK + lane) * 4);
             if (l == 0) {
                 if (A.tok_in) {          // a decode step: the row is built from the embedding tables here (one launch less per step)
                     const int bs = n < A.rows ? n / A.T : 0;
@@ -427,18 +469,15 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                         if (i == sq - s0) *reinterpret_cast<float4*>(resid + n * 4) = xv[i];
                 }
             }
-            // the first step's weights and gains are requested from LDS BEFORE the LayerNorm statistics merge (a barrier and two LDS round
-            // trips): the fills are there long before (the loader runs ahead), so their read latency hides behind the merge
             wait_fill(c, fs + 2);
             stamp_at(l, 0, 3);
             const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
             const float* gb = gbs + (wave * 64 + kk) * 4;
-            float4 wc[3], wn[3], gc, bc, gn, bn;
+            float4 wc[3], wn[3], gc, gn;
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
-            gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
-            // LayerNorm: per-wave (mean, M2) of the wave's K-slice, merged over the eight waves (Chan et al.)
-            float mean_, rstd_;
+            gc = *reinterpret_cast<const float4*>(gb);
+            // LayerNorm statistics: per-wave (mean, M2) of the wave's K-slice -> LDS; merged by the final lanes (Chan et al.)
             {
                 float s = 0.f;
 #pragma unroll
@@ -452,21 +491,6 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 }
                 m2 = kk_sum<R>(m2);
                 if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
-                cbar(c);
-                float mean = 0.f;
-#pragma unroll
-                for (int w = 0; w < kPCW; ++w) mean += stat[w * 16 + n];
-                mean *= 1.0f / (float)kPCW;
-                float M2 = 0.f, dv = 0.f;
-#pragma unroll
-                for (int w = 0; w < kPCW; ++w) {
-                    const float dm = stat[w * 16 + n] - mean;
-                    M2 += stat[kPCW * 16 + w * 16 + n];
-                    dv += dm * dm;
-                }
-                const float var = (M2 + dv * (float)(NSX * KK * 4)) * (1.0f / (float)D);
-                rstd_ = 1.0f / sqrtf(var + 1e-5f);
-                mean_ = mean;
             }
             stamp_at(l, 0, 2);
             pf32x4 acc[3];
@@ -480,10 +504,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     if (i + 1 < NSX) {
 #pragma unroll
                         for (int rg = 0; rg < 3; ++rg) wn[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (((i + 1) * STEPB) >> WB));
-                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
+                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4);
                     }
-                    const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
-                    const float x2 = (xv[i].z - mean_) * rstd_ * gc.z + bc.z, x3 = (xv[i].w - mean_) * rstd_ * gc.w + bc.w;
+                    const float x0 = xv[i].x * gc.x, x1 = xv[i].y * gc.y, x2 = xv[i].z * gc.z, x3 = xv[i].w * gc.w;
 #pragma unroll
                     for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].x, x0, acc[rg], 0, 0, 0);
 #pragma unroll
@@ -495,7 +518,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rg = 0; rg < 3; ++rg) wc[rg] = wn[rg];
-                    gc = gn; bc = bn;
+                    gc = gn;
                 }
             }
             stamp_at(l, 0, 4);
@@ -518,8 +541,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
                 }
                 const int col = wg * 12 + rg * 4;
-                const float4 bi = bpre;
-                s.x += bi.x; s.y += bi.y; s.z += bi.z; s.w += bi.w;
+                float mean, rstd;
+                ln_merge(stat, rn, (float)(NSX * KK * 4), 1.0f / (float)D, mean, rstd);
+                s.x = (s.x - mean * Spre.x) * rstd + Cpre.x; s.y = (s.y - mean * Spre.y) * rstd + Cpre.y;
+                s.z = (s.z - mean * Spre.z) * rstd + Cpre.z; s.w = (s.w - mean * Spre.w) * rstd + Cpre.w;
                 if (KVB && col >= D) {                        // a bf16 cache: k and v are rounded where they enter it, and this step's
                     s.x = bf16_round(s.x); s.y = bf16_round(s.y); s.z = bf16_round(s.z); s.w = bf16_round(s.w);      // attention reads the same values
                 }
@@ -596,7 +621,21 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             kn[0] = vn[0] = kn[1] = vn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int j0 = (wave + kPCW - 1) & (kPCW - 1);
             const int qoff = pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16;
-            if (last && j0 <= t && r0 + j0 == n) {               // (wave-uniform)
+            if (!(A.opt & 1)) {                                  // round-4 form: wave 0 stages q in LDS, one more barrier
+                if (wave == 0 && active) {
+                    pu32x4 qv[1];
+                    rgather<1>(c, brs, qoff, 0, qv, 200 + l);
+                    *reinterpret_cast<float4*>(ascr + lane * 4) = as_f4(qv[0]);
+                }
+                if (last && j0 <= t) {
+                    has_new[0] = true;
+                    pu32x4 kv[2];
+                    rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j0) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l);
+                    kn[0] = as_f4(kv[0]); vn[0] = as_f4(kv[1]);
+                }
+                cbar(c);
+                q4 = *reinterpret_cast<const float4*>(ascr + lane * 4);
+            } else if (last && j0 <= t && r0 + j0 == n) {        // (wave-uniform)
                 has_new[0] = true;
                 pu32x4 qkv[3];
                 rgather<3>(c, brs, qoff, D * 4, qkv, 200 + l, true);
@@ -825,9 +864,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const int kk = (lane >> 2) & (KK - 1), n = (lane / (KK * 4)) * 4 + (lane & 3);
             const int s0 = wave * NSX;
             float4 xv[NSX];
-            const float4 bpre = *reinterpret_cast<const float4*>(Lp->fc_b + wg * 16 + (wave & 3) * 4);
-            *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) =
-                *reinterpret_cast<const float4*>((lane < 32 ? Lp->ln2_w : Lp->ln2_b) + (s0 * KK + (lane & 31)) * 4);
+            // (LayerNorm folded into c_fc as in phase A)
+            const float4 Spre = *reinterpret_cast<const float4*>(Lp->lnS_d + wg * 16 + (wave & 3) * 4);
+            const float4 Cpre = *reinterpret_cast<const float4*>(Lp->lnC_d + wg * 16 + (wave & 3) * 4);
+            if (lane < 32) *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) = *reinterpret_cast<const float4*>(Lp->ln2_w + (s0 * KK + lane) * 4);
             {
                 pu32x4 raw[NSX];
                 rgather<NSX>(c, brs, pc + kRoffX0 * 4 + s0 * 1024 + lane * 16, 1024, raw, 400 + l, NSX <= A.poll_all);
@@ -845,16 +885,14 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                         if (i == sq - s0) *reinterpret_cast<float4*>(resid2 + (ge * kRMaxRows + n) * 4) = xv[i];
                 }
             }
-            // (first step's weights and gains requested ahead of the LayerNorm merge, as in phase A)
             wait_fill(c, fs + 3);
             stamp_at(l, 3, 3);
             const char* wbase = ring + ((s0 * STEPB + (lane & LMASK) * 16) >> WB);
             const float* gb = gbs + (wave * 64 + kk) * 4;
-            float4 wc[4], wn[4], gc, bc, gn, bn;
+            float4 wc[4], wn[4], gc, gn;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
-            gc = *reinterpret_cast<const float4*>(gb); bc = *reinterpret_cast<const float4*>(gb + 32 * 4);
-            float mean_, rstd_;
+            gc = *reinterpret_cast<const float4*>(gb);
             {
                 float s = 0.f;
 #pragma unroll
@@ -868,21 +906,6 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                 }
                 m2 = kk_sum<R>(m2);
                 if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
-                cbar(c);
-                float mean = 0.f;
-#pragma unroll
-                for (int w = 0; w < kPCW; ++w) mean += stat[w * 16 + n];
-                mean *= 1.0f / (float)kPCW;
-                float M2 = 0.f, dv = 0.f;
-#pragma unroll
-                for (int w = 0; w < kPCW; ++w) {
-                    const float dm = stat[w * 16 + n] - mean;
-                    M2 += stat[kPCW * 16 + w * 16 + n];
-                    dv += dm * dm;
-                }
-                const float var = (M2 + dv * (float)(NSX * KK * 4)) * (1.0f / (float)D);
-                rstd_ = 1.0f / sqrtf(var + 1e-5f);
-                mean_ = mean;
             }
             pf32x4 acc[4];
 #pragma unroll
@@ -896,10 +919,9 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     if (i + 1 < NSX) {
 #pragma unroll
                         for (int rg = 0; rg < 4; ++rg) wn[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot + (((i + 1) * STEPB) >> WB));
-                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4); bn = *reinterpret_cast<const float4*>(gb + (32 + (i + 1) * KK) * 4);
+                        gn = *reinterpret_cast<const float4*>(gb + (i + 1) * KK * 4);
                     }
-                    const float x0 = (xv[i].x - mean_) * rstd_ * gc.x + bc.x, x1 = (xv[i].y - mean_) * rstd_ * gc.y + bc.y;
-                    const float x2 = (xv[i].z - mean_) * rstd_ * gc.z + bc.z, x3 = (xv[i].w - mean_) * rstd_ * gc.w + bc.w;
+                    const float x0 = xv[i].x * gc.x, x1 = xv[i].y * gc.y, x2 = xv[i].z * gc.z, x3 = xv[i].w * gc.w;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].x, x0, acc[rg], 0, 0, 0);
 #pragma unroll
@@ -911,7 +933,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) wc[rg] = wn[rg];
-                    gc = gn; bc = bn;
+                    gc = gn;
                 }
             }
             stamp_at(l, 3, 4);
@@ -933,8 +955,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     const float4 p = *reinterpret_cast<const float4*>(red + ((w * 4 + rg) * kRMaxRows + rn) * 4);
                     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
                 }
-                const float4 bi = bpre;
-                s.x = gelu_new(s.x + bi.x); s.y = gelu_new(s.y + bi.y); s.z = gelu_new(s.z + bi.z); s.w = gelu_new(s.w + bi.w);
+                float mean, rstd;
+                ln_merge(stat, rn, (float)(NSX * KK * 4), 1.0f / (float)D, mean, rstd);
+                s.x = gelu_new((s.x - mean * Spre.x) * rstd + Cpre.x); s.y = gelu_new((s.y - mean * Spre.y) * rstd + Cpre.y);
+                s.z = gelu_new((s.z - mean * Spre.z) * rstd + Cpre.z); s.w = gelu_new((s.w - mean * Spre.w) * rstd + Cpre.w);
                 stamp_at(l, 3, 7);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const int q = wg * 4 + rg;                   // k-quad of the hidden units [16 wg + 4 rg, +4)
