@@ -29,6 +29,9 @@ struct GemmEpi {
     int ldr;
     long long resid_batch_stride;
     long long resid_batch_stride2; // two-level batches (GemmArgs.batch_inner): stride of the outer index
+    int resid_fm16;          // skinny kernels: `resid` is an FM16 matrix of row length N (the Perceiver keeps its latents fragment-major)
+    int geglu;               // skinny kernels: columns come in (x_j, gate_j) pairs (weights interleaved at bind time); the epilogue stores
+                             // gelu_erf(gate_j) * x_j as column j of an FM16 matrix of row length N / 2 (perceiver_encoder.py:205-208)
     const float* resid2;     // second residual with the layout of `resid` (HiFi-GAN resblock sum), or null
     float out_scale;         // 0 = none; otherwise the stored value is multiplied by it
     // GPT QKV scatter (prefill): n < d -> q[m][n]; else K/V cache rows
@@ -189,7 +192,7 @@ __device__ __forceinline__ void gemm_store_pre(const GemmArgs& G, int m, int n, 
         }
         return;
     }
-    if (e.resid) v += e.resid[(size_t)m * e.ldr + n];
+    if (e.resid) v += e.resid[e.resid_fm16 ? fm16_index(m, n, G.N) : (size_t)m * e.ldr + n];
     if (e.resid2) v += e.resid2[(size_t)m * e.ldr + n];
     if (e.out_scale != 0.f) v *= e.out_scale;
     if (e.c_fm16) { G.C[fm16_index(m, n, G.N)] = v; return; }
@@ -221,8 +224,12 @@ __device__ __forceinline__ void gemm_store4_pre(const GemmArgs& G, int m, int n,
         }
         return;
     }
+    if (e.geglu) {          // (x0, gate0, x1, gate1) -> columns n / 2, n / 2 + 1 of the FM16 output (row length N / 2)
+        *reinterpret_cast<float2*>(G.C + fm16_index(m, n >> 1, G.N >> 1)) = make_float2(gelu_erf(v.y) * v.x, gelu_erf(v.w) * v.z);
+        return;
+    }
     if (e.resid) {
-        const float4 r = *reinterpret_cast<const float4*>(e.resid + (size_t)m * e.ldr + n);
+        const float4 r = *reinterpret_cast<const float4*>(e.resid + (e.resid_fm16 ? fm16_index(m, n, G.N) : (size_t)m * e.ldr + n));
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
     if (e.resid2) {

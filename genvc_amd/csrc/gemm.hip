@@ -339,6 +339,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const GemmArgs G) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += red[w][t][q * 64 + lane];
+            if (G.SK == 1 && G.e.geglu) {       // (x_j, gate_j) sit in neighbouring lanes: the even lane stores gelu_erf(gate_j) * x_j
+                v += pre.bias.x;
+                const float other = __shfl_xor(v, 1);
+                if (m < G.M && !(lane & 1)) G.C[fm16_index(m, n >> 1, G.N >> 1)] = gelu_erf(other) * v;
+                continue;
+            }
             if (m < G.M) {
                 if (G.SK > 1) G.work[((size_t)blockIdx.y * G.M + m) * G.N + n] = v;
                 else gemm_store_pre(G, m, n, v, pre);

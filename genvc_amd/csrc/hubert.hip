@@ -16,11 +16,11 @@
 #include <vector>
 
 #include "conv_lds.h"
+#include "attn64.h"
 #include <algorithm>
 
 namespace gvc {
 
-typedef float hb_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kC0Chunk = 32;          // output frames per conv0 workgroup (= GroupNorm partial-statistics chunk)
 
 // Conv1d weight [Co][Ci][k] -> [Co][k*Ci] with column j*Ci + ci
@@ -196,115 +196,6 @@ static __global__ __launch_bounds__(64) void k_hb_frame_mask(const float* wav, i
     for (int i = lane; i < chunk; i += 64) nz |= (p[i] != 0.f);
     nz = __any(nz);
     if (lane == 0) fmask[b * F + f] = nz ? 0 : 1;
-}
-
-// Non-causal multi-head attention, head_dim 64, fp32.  qkv [B*T][3E] (q | k | v, head h at columns h*64), out [B*T][E].
-// grid (ceil(T/16), H, B); the 4 waves of a workgroup share 16 queries and take every 4th 16-key tile, merged
-// through LDS at the end.  Per tile:   S^T[key][q] = sum_d K[key][d] Q[q][d]      (A = K fragment, B = Q fragment)
-//                                      O^T[d][q] += sum_key V[key][d] P[key][q]   (A = V fragment, B = P = the S^T registers)
-// lane (r = lane%16, g = lane/16) holds S^T rows key0 + 4g + i (i = 0..3) for query q0 + r, which is exactly the
-// B-operand layout of the second product when its k-step i is mapped to keys {key0 + 4g + i}.  The d index of the
-// first product is permuted (d = 16s + 4g + comp) and the row index of O^T is permuted (row m of tile mt <-> d = 4m + mt)
-// so that every fragment load is a float4.
-// fmask [B][T]: keys of padding frames are excluded (fairseq MultiheadAttention key_padding_mask: scores -> -inf)
-static __global__ __launch_bounds__(256) void k_hb_attention(const float* qkv, float* out, int T, int E, float scale, int out_fm16,
-                                                            const int32_t* fmask) {
-    __shared__ float sm[4][16], sl[4][16];
-    __shared__ __attribute__((aligned(16))) float so[4][16][68];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
-    const size_t ld = 3 * (size_t)E;
-    const float* base = qkv + (size_t)b * T * ld + h * 64;
-    const float* kbase = base + E;
-    const float* vbase = base + 2 * E;
-    const int qi = min(q0 + r, T - 1);
-    float4 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = *reinterpret_cast<const float4*>(base + (size_t)qi * ld + 16 * s + 4 * g);
-        qf[s].x *= scale; qf[s].y *= scale; qf[s].z *= scale; qf[s].w *= scale;
-    }
-    hb_f32x4 o[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) o[mt] = {0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
-    const int ntile = (T + 15) >> 4;
-    for (int kt = wave; kt < ntile; kt += 4) {
-        const int key0 = kt * 16;
-        const int kr = min(key0 + r, T - 1);
-        float4 kf[4], vf[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const float4*>(kbase + (size_t)kr * ld + 16 * s + 4 * g);
-        int kmask[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int vr = min(key0 + 4 * g + i, T - 1);
-            vf[i] = *reinterpret_cast<const float4*>(vbase + (size_t)vr * ld + 4 * r);
-            kmask[i] = fmask[b * T + vr];
-        }
-        hb_f32x4 st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].x, qf[s].x, st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].y, qf[s].y, st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].z, qf[s].z, st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s].w, qf[s].w, st, 0, 0, 0);
-        }
-        float p[4];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            p[i] = (key0 + 4 * g + i < T && !kmask[i]) ? st[i] : -INFINITY;
-            tmax = fmaxf(tmax, p[i]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float mnew = fmaxf(m, tmax);
-        // a tile (or everything so far) made of padding keys only leaves mnew at -inf: nothing to add, nothing to rescale
-        const bool none = mnew == -INFINITY;
-        const float alpha = none ? 1.0f : expf(m - mnew);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { p[i] = none ? 0.f : expf(p[i] - mnew); psum += p[i]; }
-        l = l * alpha + psum;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) o[mt] *= alpha;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i].x, p[i], o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i].y, p[i], o[1], 0, 0, 0);
-            o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i].z, p[i], o[2], 0, 0, 0);
-            o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i].w, p[i], o[3], 0, 0, 0);
-        }
-        m = mnew;
-    }
-    // per-lane l covers this lane's keys only
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    if (g == 0) { sm[wave][r] = m; sl[wave][r] = l; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)      // o[mt][i] = O[q0 + r][16g + 4i + mt]
-        *reinterpret_cast<float4*>(&so[wave][r][16 * g + 4 * i]) = make_float4(o[0][i], o[1][i], o[2][i], o[3][i]);
-    __syncthreads();
-    const int qr = tid >> 4, dc = (tid & 15) * 4;
-    if (q0 + qr < T) {
-        float M = sm[0][qr];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) M = fmaxf(M, sm[w][qr]);
-        float L = 0.f;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = sm[w][qr] == -INFINITY ? 0.f : expf(sm[w][qr] - M);
-            L += sl[w][qr] * f;
-            const float4 ov = *reinterpret_cast<const float4*>(&so[w][qr][dc]);
-            acc.x += ov.x * f; acc.y += ov.y * f; acc.z += ov.z * f; acc.w += ov.w * f;
-        }
-        const float inv = 1.0f / L;
-        acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
-        if (out_fm16) *reinterpret_cast<float4*>(out + fm16_index(b * T + q0 + qr, h * 64 + dc, E)) = acc;
-        else *reinterpret_cast<float4*>(out + ((size_t)b * T + q0 + qr) * E + h * 64 + dc) = acc;
-    }
 }
 
 }  // namespace gvc
@@ -670,7 +561,7 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
         for (int l = 0; l < D.n_layers; ++l) {
             const HbLayer& L = c->layers[l];
             if ((rc = sk_gemm(L.qkv, c->xf, c->qkv, ACT_NONE, 0, 1))) return rc;
-            hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->af, F, E, 0.125f, 1, c->fmask);
+            hipLaunchKernelGGL(k_attn64_mfma<true>, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->qkv + E, c->qkv + 2 * E, (long long)3 * E, (long long)F * 3 * E, F, F, c->af, F, E, 0.125f, 1, c->fmask);
             GVC_LAUNCH_CHECK();
             if ((rc = sk_gemm(L.out, c->af, c->tmp, ACT_NONE, 0, sk_out, c->x))) return rc;
             post_ln(L.out, L.ln1, sk_out);
@@ -688,7 +579,7 @@ static int hb_body(gvc_hubert* c, int B, int T, hipStream_t s) {
     for (int l = 0; l < D.n_layers; ++l) {
         const HbLayer& L = c->layers[l];
         if ((rc = hb_linear(c, L.qkv, c->x, c->qkv, rows, ACT_NONE, nullptr, s))) return rc;
-        hipLaunchKernelGGL(k_hb_attention, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->att, F, E, 0.125f, 0, c->fmask);
+        hipLaunchKernelGGL(k_attn64_mfma<true>, dim3(cdiv(F, 16), D.n_heads, B), dim3(256), 0, s, c->qkv, c->qkv + E, c->qkv + 2 * E, (long long)3 * E, (long long)F * 3 * E, F, F, c->att, F, E, 0.125f, 0, c->fmask);
         GVC_LAUNCH_CHECK();
         if ((rc = hb_linear(c, L.out, c->att, c->tmp, rows, ACT_NONE, c->x, s))) return rc;
         hipLaunchKernelGGL(k_hb_ln_rows, dim3(rows), dim3(256), 0, s, c->tmp, (long long)F * E, c->x, (long long)F * E, F, E,

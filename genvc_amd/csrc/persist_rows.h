@@ -477,22 +477,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
             gc = *reinterpret_cast<const float4*>(gb);
-            // LayerNorm statistics: per-wave (mean, M2) of the wave's K-slice -> LDS; merged by the final lanes (Chan et al.)
-            {
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSX; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-                const float mw = kk_sum<R>(s) * (1.0f / (float)(NSX * KK * 4));
-                float m2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSX; ++i) {
-                    const float a0 = xv[i].x - mw, a1 = xv[i].y - mw, a2 = xv[i].z - mw, a3 = xv[i].w - mw;
-                    m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                }
-                m2 = kk_sum<R>(m2);
-                if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
-            }
-            stamp_at(l, 0, 2);
+            // LayerNorm statistics: per-wave (mean, M2) of the wave's K-slice -> LDS, merged by the final lanes (Chan et al.).  Their three
+            // dependent pieces (sum + lane reduction, squared deviations, lane reduction + store) ride in the shadow of the first three
+            // MFMA steps: the matrix pipe is busy with the step's 12 instructions while the vector ALU does them
+            float ln_mw = 0.f, ln_m2 = 0.f;
             pf32x4 acc[3];
 #pragma unroll
             for (int rg = 0; rg < 3; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
@@ -515,6 +503,24 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].z, x2, acc[rg], 0, 0, 0);
 #pragma unroll
                     for (int rg = 0; rg < 3; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].w, x3, acc[rg], 0, 0, 0);
+                    // LayerNorm statistics of the wave's K-slice, one dependent piece per step
+                    if (i == 0) {
+                        float sm = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NSX; ++j) sm += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+                        ln_mw = kk_sum<R>(sm) * (1.0f / (float)(NSX * KK * 4));
+                    }
+                    if (i == 1) {
+#pragma unroll
+                        for (int j = 0; j < NSX; ++j) {
+                            const float a0 = xv[j].x - ln_mw, a1 = xv[j].y - ln_mw, a2 = xv[j].z - ln_mw, a3 = xv[j].w - ln_mw;
+                            ln_m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                        }
+                    }
+                    if (i == 2) {
+                        ln_m2 = kk_sum<R>(ln_m2);
+                        if (kk == 0) { stat[wave * 16 + n] = ln_mw; stat[kPCW * 16 + wave * 16 + n] = ln_m2; }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rg = 0; rg < 3; ++rg) wc[rg] = wn[rg];
@@ -893,24 +899,10 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) wc[rg] = ldw4<WB>(wbase + (size_t)((fs + rg) & rmask) * kPSlot);
             gc = *reinterpret_cast<const float4*>(gb);
-            {
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSX; ++i) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
-                const float mw = kk_sum<R>(s) * (1.0f / (float)(NSX * KK * 4));
-                float m2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < NSX; ++i) {
-                    const float a0 = xv[i].x - mw, a1 = xv[i].y - mw, a2 = xv[i].z - mw, a3 = xv[i].w - mw;
-                    m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                }
-                m2 = kk_sum<R>(m2);
-                if (kk == 0) { stat[wave * 16 + n] = mw; stat[kPCW * 16 + wave * 16 + n] = m2; }
-            }
+            float ln_mw = 0.f, ln_m2 = 0.f;          // (statistics in the shadow of the MFMA steps, as in phase A)
             pf32x4 acc[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) acc[rg] = (pf32x4){0.f, 0.f, 0.f, 0.f};
-            stamp_at(l, 3, 2);
             {
                 // one step (four MFMAs per row group) at a time, the next step's operands requested a step ahead: left alone, the
                 // scheduler hoists every LDS read of the unrolled loop to its top (128 registers of weights) and spills
@@ -930,6 +922,24 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
                     for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].z, x2, acc[rg], 0, 0, 0);
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) acc[rg] = __builtin_amdgcn_mfma_f32_4x4x1f32(wc[rg].w, x3, acc[rg], 0, 0, 0);
+                    // LayerNorm statistics of the wave's K-slice, one dependent piece per step
+                    if (i == 0) {
+                        float sm = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NSX; ++j) sm += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+                        ln_mw = kk_sum<R>(sm) * (1.0f / (float)(NSX * KK * 4));
+                    }
+                    if (i == 1) {
+#pragma unroll
+                        for (int j = 0; j < NSX; ++j) {
+                            const float a0 = xv[j].x - ln_mw, a1 = xv[j].y - ln_mw, a2 = xv[j].z - ln_mw, a3 = xv[j].w - ln_mw;
+                            ln_m2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                        }
+                    }
+                    if (i == 2) {
+                        ln_m2 = kk_sum<R>(ln_m2);
+                        if (kk == 0) { stat[wave * 16 + n] = ln_mw; stat[kPCW * 16 + wave * 16 + n] = ln_m2; }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) wc[rg] = wn[rg];

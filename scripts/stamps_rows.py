@@ -39,7 +39,7 @@ print(f"B={B} keys~{32 + Tc + 3} {wd}: workgroup 0, mean us per stage (layers 2.
       "  ".join(f"{names[i//2]}{' wait' if i%2==0 else ' work'} {per[i]:.2f}" for i in range(10)))
 print(f"mean per layer {np.diff(d[:, -1]).mean():.2f} us;  waits {per[0::2].sum():.2f}  work {per[1::2].sum():.2f}")
 # attribution of the work term, workgroup 0, mean over layers 2..: consecutive stamps in program order
-order = {0: [0, 3, 2, 4, 5, 6, 7, 1], 1: [0, 4, 5, 6, 7, 1], 2: [0, 3, 4, 5, 6, 7, 1], 3: [0, 3, 2, 4, 5, 6, 7, 1], 4: [0, 3, 4, 5, 6, 7, 1]}
+order = {0: [0, 3, 4, 5, 6, 7, 1], 1: [0, 4, 5, 6, 7, 1], 2: [0, 3, 4, 5, 6, 7, 1], 3: [0, 3, 4, 5, 6, 7, 1], 4: [0, 3, 4, 5, 6, 7, 1]}
 label = {0: "gathered", 1: "published", 2: "LN merged", 3: "fills ok", 4: "MFMA done", 5: "partials in LDS", 6: "barrier", 7: "final ready"}
 labelB = {2: "own gathers", 0: "barrier (q ready)", 4: "scores+fold", 5: "partials in LDS", 6: "barrier", 7: "merged", 1: "published"}
 tot = {}
