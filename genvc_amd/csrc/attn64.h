@@ -10,7 +10,8 @@ typedef float hb_f32x4 __attribute__((ext_vector_type(4)));
 // stride `ld` and batch stride `bs` (head h at columns h*64 of each); query rows 0 .. Tq-1, key rows 0 .. Tk-1 of a batch element;
 // out [B * out_rows][E] row-major or FM16 (row b * out_rows + query).  Users: ContentVec's self-attention (q | k | v side by side in
 // one [T][3E] buffer, Tq = Tk = T, padding-frame mask) and the Perceiver's cross-attention (32 latent queries over latents + context).
-// grid (ceil(Tq/16), H, B); the 4 waves of a workgroup share 16 queries and take every 4th 16-key tile, merged
+// grid (ceil(Tq/16), H, B); the NW waves of a workgroup (4: ContentVec, hundreds of workgroups; 16: the Perceiver, whose 2 query
+// tiles x 8 heads are all the workgroups there are) share 16 queries and take every NW-th 16-key tile, merged
 // through LDS at the end.  Per tile:   S^T[key][q] = sum_d K[key][d] Q[q][d]      (A = K fragment, B = Q fragment)
 //                                      O^T[d][q] += sum_key V[key][d] P[key][q]   (A = V fragment, B = P = the S^T registers)
 // lane (r = lane%16, g = lane/16) holds S^T rows key0 + 4g + i (i = 0..3) for query q0 + r, which is exactly the
@@ -18,11 +19,11 @@ typedef float hb_f32x4 __attribute__((ext_vector_type(4)));
 // first product is permuted (d = 16s + 4g + comp) and the row index of O^T is permuted (row m of tile mt <-> d = 4m + mt)
 // so that every fragment load is a float4.
 // MASK: fmask [B][Tk], keys of padding frames are excluded (fairseq MultiheadAttention key_padding_mask: scores -> -inf)
-template <bool MASK>
-__global__ __launch_bounds__(256) void k_attn64_mfma(const float* qb, const float* kb, const float* vb, long long ld, long long bs, int Tq,
+template <bool MASK, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_attn64_mfma(const float* qb, const float* kb, const float* vb, long long ld, long long bs, int Tq,
                                                      int Tk, float* out, int out_rows, int E, float scale, int out_fm16, const int32_t* fmask) {
-    __shared__ float sm[4][16], sl[4][16];
-    __shared__ __attribute__((aligned(16))) float so[4][16][68];
+    __shared__ float sm[NW][16], sl[NW][16];
+    __shared__ __attribute__((aligned(16))) float so[NW][16][68];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
     const float* base = qb + (size_t)b * bs + h * 64;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void k_attn64_mfma(const float* qb, const floa
     for (int mt = 0; mt < 4; ++mt) o[mt] = {0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
     const int ntile = (T + 15) >> 4;
-    for (int kt = wave; kt < ntile; kt += 4) {
+    for (int kt = wave; kt < ntile; kt += NW) {
         const int key0 = kt * 16;
         const int kr = min(key0 + r, T - 1);
         float4 kf[4], vf[4];
@@ -99,14 +100,14 @@ __global__ __launch_bounds__(256) void k_attn64_mfma(const float* qb, const floa
         *reinterpret_cast<float4*>(&so[wave][r][16 * g + 4 * i]) = make_float4(o[0][i], o[1][i], o[2][i], o[3][i]);
     __syncthreads();
     const int qr = tid >> 4, dc = (tid & 15) * 4;
-    if (q0 + qr < Tq) {
+    if (tid < 256 && q0 + qr < Tq) {
         float M = sm[0][qr];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) M = fmaxf(M, sm[w][qr]);
+        for (int w = 1; w < NW; ++w) M = fmaxf(M, sm[w][qr]);
         float L = 0.f;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float f = sm[w][qr] == -INFINITY ? 0.f : expf(sm[w][qr] - M);
             L += sl[w][qr] * f;
             const float4 ov = *reinterpret_cast<const float4*>(&so[w][qr][dc]);

@@ -88,8 +88,10 @@ struct gvc_perceiver {
     float *C = nullptr, *kv = nullptr, *X = nullptr, *o = nullptr, *g = nullptr, *xp = nullptr, *work = nullptr, *tmp = nullptr;
     long long work_cap = 0;
     std::map<long long, hipGraphExec_t> graphs;    // (B, F) -> captured body of the forward (context-owned buffers only)
-    hipStream_t cap_stream = nullptr;
+    hipStream_t cap_stream = nullptr, side_stream = nullptr;   // capture: the main chain, and the branch the later layers' context keys / values run on
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int use_graph = 1;               // GVC_PERCEIVER_GRAPH=0: eager launches
+    int fork = 0;                    // GVC_PERCEIVER_FORK=1: layers 1..'s context keys / values on a parallel branch of the graph (measured: slower)
 };
 
 extern "C" int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceiver** out) {
@@ -140,7 +142,11 @@ extern "C" int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceive
     GVC_CHECK_HIP(hipMalloc((void**)&c->work, (size_t)c->work_cap * sizeof(float)));
     GVC_CHECK_HIP(hipMalloc((void**)&c->tmp, 2 * fp * d * sizeof(float)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (getenv("GVC_PERCEIVER_GRAPH")) c->use_graph = atoi(getenv("GVC_PERCEIVER_GRAPH"));
+    if (getenv("GVC_PERCEIVER_FORK")) c->fork = atoi(getenv("GVC_PERCEIVER_FORK"));
     gemm_init_attributes();
     *out = c;
     return GVC_OK;
@@ -150,6 +156,9 @@ extern "C" int gvc_perceiver_destroy(gvc_perceiver* c) {
     if (!c) return GVC_OK;
     for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (void* p : {(void*)c->wbase, (void*)c->C, (void*)c->X, (void*)c->kv, (void*)c->o, (void*)c->g, (void*)c->xp, (void*)c->work,
                     (void*)c->tmp})
         if (p) hipFree(p);
@@ -247,7 +256,8 @@ static int perc_stage_in(gvc_perceiver* c, const float* x, int B, int F, hipStre
     return GVC_OK;
 }
 
-static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
+// `side`: a second stream of the same capture (null: everything in order on s)
+static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s, hipStream_t side) {
     const int d = c->dm.dim, in = c->inner, NL = c->dm.num_latents, R = NL + F, depth = c->dm.depth, fp = c->ffi_p;
     const int ldkv = depth * 3 * in;                  // floats per row of KV: [depth][q | k | v]
     int rc;
@@ -260,19 +270,34 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
         G.M = F; G.N = d; G.K = c->ctx_p; G.work = c->work; G.e.bias = c->proj_b;
         if ((rc = launch_gemm_cap(G, B, c->work_cap, s))) return rc;
     }
-    // keys / values of the context rows for ALL layers: one GEMM, batch = (batch element, layer); layer l's to_kv rows sit behind its
-    // to_q rows in the stacked matrix, its k | v columns behind its q columns in a KV row
-    memset(&G, 0, sizeof(G));
-    G.batch_inner = depth;
-    G.A = c->C + (size_t)NL * d; G.lda = d; G.a_batch_stride = 0; G.a_batch_stride2 = (long long)R * d;
-    G.Wt = c->layers[0].wqkv + (size_t)in * d; G.ldw = d; G.w_batch_stride = (long long)3 * in * d;
-    G.C = c->kv + (size_t)NL * ldkv + in; G.ldc = ldkv; G.c_batch_stride = 3 * in; G.c_batch_stride2 = (long long)R * ldkv;
-    G.M = F; G.N = 2 * in; G.K = d; G.work = c->work;
-    if ((rc = launch_gemm_cap(G, B * depth, c->work_cap, s))) return rc;
-    // X = latents, fragment-major, one copy per batch element
-    hipLaunchKernelGGL(k_rep_latents, dim3(8), dim3(256), 0, s, c->lat_fm, c->X, NL * d);
-    if (B > 1) hipLaunchKernelGGL(k_rep_latents, dim3(8, B - 1), dim3(256), 0, s, c->lat_fm, c->X + (size_t)NL * d, NL * d);
-    GVC_LAUNCH_CHECK();
+    // keys / values of the context rows: they do not change across the layers, so they are computed up front by the tiled MFMA GEMM,
+    // batch = (batch element, layer); layer l's to_kv rows sit behind its to_q rows in the stacked matrix, its k | v columns behind its
+    // q columns in a KV row.  One GEMM over (batch element, layer).  GVC_PERCEIVER_FORK=1 (measured, not the default: 275 vs 266 us per
+    // forward -- the branch's GEMM and the latent chain slow each other down): layer 0's first on the main chain, the other layers' as
+    // one GEMM on a parallel branch of the graph beside layer 0's latent path, joined in front of layer 1's attention
+    auto ctx_kv = [&](int l0, int nl, hipStream_t st) {
+        memset(&G, 0, sizeof(G));
+        G.batch_inner = nl;
+        G.A = c->C + (size_t)NL * d; G.lda = d; G.a_batch_stride = 0; G.a_batch_stride2 = (long long)R * d;
+        G.Wt = c->layers[l0].wqkv + (size_t)in * d; G.ldw = d; G.w_batch_stride = (long long)3 * in * d;
+        G.C = c->kv + (size_t)NL * ldkv + (size_t)l0 * 3 * in + in; G.ldc = ldkv; G.c_batch_stride = 3 * in; G.c_batch_stride2 = (long long)R * ldkv;
+        G.M = F; G.N = 2 * in; G.K = d; G.work = nullptr;             // (no split-K: the branch must not share the work buffer)
+        return launch_gemm_cap(G, B * nl, 0, st);
+    };
+    const bool fork = side != nullptr && depth > 1 && c->fork;
+    if (fork) {
+        GVC_CHECK_HIP(hipEventRecord(c->ev_fork, s));
+        GVC_CHECK_HIP(hipStreamWaitEvent(side, c->ev_fork, 0));
+        if ((rc = ctx_kv(1, depth - 1, side))) return rc;
+        GVC_CHECK_HIP(hipEventRecord(c->ev_join, side));
+        if ((rc = ctx_kv(0, 1, s))) return rc;
+    } else if ((rc = ctx_kv(0, depth, s))) return rc;
+    // X = latents, fragment-major, one copy per batch element.  One batch element (the usual call: one reference chunk): no copy --
+    // layer 0 reads the parameter itself (A operand of its q | k | v GEMM, residual of its to_out) and writes X
+    if (B > 1) {
+        hipLaunchKernelGGL(k_rep_latents, dim3(8, B), dim3(256), 0, s, c->lat_fm, c->X, NL * d);
+        GVC_LAUNCH_CHECK();
+    }
 
     auto skinny = [&](const float* A_fm, int M, const float* W_fm, int N, int K, float* Cp, int ldc) {
         memset(&G, 0, sizeof(G));
@@ -282,13 +307,14 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
         const PercLayer& ly = c->layers[l];
         // q | k | v of the latent rows: one GEMM per batch element (its 32 rows are rows 0..31 of that element's KV block)
         for (int b = 0; b < B; ++b) {
-            skinny(c->X + (size_t)b * NL * d, NL, ly.f_qkv, 3 * in, d, c->kv + (size_t)b * R * ldkv + (size_t)l * 3 * in, ldkv);
+            skinny(B == 1 && l == 0 ? c->lat_fm : c->X + (size_t)b * NL * d, NL, ly.f_qkv, 3 * in, d, c->kv + (size_t)b * R * ldkv + (size_t)l * 3 * in, ldkv);
             if ((rc = launch_gemm_skinny(G, 1, c->work_cap, s))) return rc;
         }
         // cross-attention of the 32 latent queries over latents + context, output fragment-major [B * 32][inner]
+        if (fork && l == 1) GVC_CHECK_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
         {
             const float* qb = c->kv + (size_t)l * 3 * in;
-            hipLaunchKernelGGL(k_attn64_mfma<false>, dim3(NL / 16, c->dm.heads, B), dim3(256), 0, s, qb, qb + in, qb + 2 * in, (long long)ldkv,
+            hipLaunchKernelGGL((k_attn64_mfma<false, 16>), dim3(NL / 16, c->dm.heads, B), dim3(1024), 0, s, qb, qb + in, qb + 2 * in, (long long)ldkv,
                                (long long)R * ldkv, NL, R, c->o, NL, in, 1.0f / sqrtf((float)c->dm.dim_head), 1, (const int32_t*)nullptr);
             GVC_LAUNCH_CHECK();
         }
@@ -298,7 +324,7 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
             float* Xg = c->X + (size_t)b0 * NL * d;
             // latents += o @ to_out^T
             skinny(c->o + (size_t)b0 * NL * in, M, ly.f_out, d, in, Xg, d);
-            G.e.c_fm16 = 1; G.e.resid = Xg; G.e.resid_fm16 = 1; G.e.ldr = d;
+            G.e.c_fm16 = 1; G.e.resid = B == 1 && l == 0 ? c->lat_fm : Xg; G.e.resid_fm16 = 1; G.e.ldr = d;
             if ((rc = launch_gemm_skinny(G, 1, c->work_cap, s))) return rc;
             // feed-forward: Linear -> GEGLU (in the epilogue) -> Linear, residual
             skinny(Xg, M, ly.f_ff1, 2 * fp, d, c->g + (size_t)b0 * NL * fp, fp);
@@ -323,7 +349,7 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
     if ((rc = perc_prepare(c, s))) return rc;
     if ((rc = perc_stage_in(c, x, B, F, s))) return rc;
     if (!c->use_graph) {
-        if ((rc = perc_launch(c, B, F, s))) return rc;
+        if ((rc = perc_launch(c, B, F, s, nullptr))) return rc;
     } else {
         // the body works on context-owned buffers only: one graph per (B, F), whatever the caller's pointers
         const long long key = (long long)B * 100000 + F;
@@ -331,7 +357,7 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
         if (it == c->graphs.end()) {
             hipGraph_t graph = nullptr;
             GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-            rc = perc_launch(c, B, F, c->cap_stream);
+            rc = perc_launch(c, B, F, c->cap_stream, c->side_stream);
             hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             GVC_CHECK_HIP(e);

@@ -76,8 +76,9 @@ class GenVCModel(nn.Module):
             chunk = audio[:, i:i + sr * chunk_length]
             if chunk.size(-1) < sr * 0.33:
                 continue
-            mel = self.torch_mel_spectrogram_style_encoder(chunk.to(self.device).contiguous())
-            embs.append(self.gpt.get_style_emb(mel, None))
+            # (the mel kernel also writes the frames-major copy the Perceiver reads: get_style_emb's permute(0, 2, 1).contiguous() is free)
+            mel, mel_fm = self.torch_mel_spectrogram_style_encoder(chunk.to(self.device).contiguous(), frames_major=True)
+            embs.append(self.gpt.get_style_emb(mel, None, frames_major=mel_fm))
         return torch.stack(embs).mean(dim=0).transpose(1, 2).contiguous()
 
     def get_gpt_cond_latents_async(self, audio, sr, length=30, chunk_length=6):

@@ -144,15 +144,17 @@ class GPT(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
-    def get_style_emb(self, cond_input, return_latent=False, seq_lens=None):
-        """cond_input (b,80,s) or (b,1,80,s) -> (b, d, 32)   (reference gpt.py:351-373)"""
+    def get_style_emb(self, cond_input, return_latent=False, seq_lens=None, frames_major=None):
+        """cond_input (b,80,s) or (b,1,80,s) -> (b, d, 32)   (reference gpt.py:351-373).  frames_major (extension): the same mel as
+        (b,s,80), which the mel kernel writes alongside -- saves the permute(0, 2, 1).contiguous() copy in front of the Perceiver"""
         if return_latent:
             return cond_input.unsqueeze(1)
         if cond_input.ndim == 4:
             cond_input = cond_input.squeeze(1)
         if seq_lens is not None:
             raise NotImplementedError("perceiver masks are a training-only path")
-        return self.conditioning_perceiver(cond_input.permute(0, 2, 1).contiguous()).transpose(1, 2)
+        x = frames_major if frames_major is not None else cond_input.permute(0, 2, 1).contiguous()
+        return self.conditioning_perceiver(x).transpose(1, 2)
 
     @torch.inference_mode()
     def compute_embeddings(self, cond_latents, text_inputs):
