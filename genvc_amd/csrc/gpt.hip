@@ -763,7 +763,7 @@ static int persist_prepare(gvc_gpt* c) {
         hipMalloc((void**)&c->p_epoch, 16 * sizeof(unsigned)) != hipSuccess || hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned)) != hipSuccess)
         return unavailable();
     if (getenv("GVC_PERSIST_STAMPS")) {
-        const size_t nb = (size_t)(20 * (L + 2) + 2 * 5 * kPG) * sizeof(unsigned long long);
+        const size_t nb = (size_t)(20 * (L + 2) + 2 * 5 * kPG + 8 * kPG) * sizeof(unsigned long long);
         if (hipMalloc((void**)&c->p_dbg, nb) != hipSuccess || hipMemset(c->p_dbg, 0, nb) != hipSuccess) return unavailable();
     }
     const int ng_hd = kPCW * 256;                       // lane-group states of the attention phase: [kPCW * 64 / (hd / 4)][hd]
@@ -817,6 +817,10 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     static const int loader_depth = getenv("GVC_PERSIST_LOADER_DEPTH") ? atoi(getenv("GVC_PERSIST_LOADER_DEPTH")) : 1;
     static const int ln_one_pass = getenv("GVC_PERSIST_LN_ONE_PASS") ? atoi(getenv("GVC_PERSIST_LN_ONE_PASS")) : 0;
     A.poll_b = poll_b; A.poll_h = poll_h; A.loader_depth = loader_depth; A.ln_one_pass = ln_one_pass;
+    static const int dbg_layer = getenv("GVC_PERSIST_STAMP_LAYER") ? atoi(getenv("GVC_PERSIST_STAMP_LAYER")) : 2;
+    A.dbg_layer = dbg_layer;
+    static const int nosent = getenv("GVC_PERSIST_NOSENT") ? atoi(getenv("GVC_PERSIST_NOSENT")) : 0;
+    A.nosent = nosent;
     if (c->bf16) A.head_w = reinterpret_cast<const float*>(c->head_h);
     void* kargs[] = {&A};
     GVC_CHECK_HIP(hipLaunchKernel((const void*)persist_kernel(c), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->p_lds, s));
@@ -1589,7 +1593,7 @@ extern "C" int gvc_gpt_debug_stamps(gvc_gpt* c, unsigned long long* host_out, in
     }
     if (c && c->p_dbg && max_launches < 0) {     // stamps of the last one-launch decode step (layout: persist_kernel.h)
         (void)hipDeviceSynchronize();
-        const int n = 20 * (c->dm.n_layer + 2) + 2 * 5 * kPG;
+        const int n = 20 * (c->dm.n_layer + 2) + 2 * 5 * kPG + 8 * kPG;
         (void)hipMemcpy(host_out, c->p_dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         return n;
     }

@@ -76,6 +76,8 @@ struct PersistArgs {
     int hvec_floats, ascr_floats;
     unsigned long long* dbg;        // nullable: wall-clock stamps
     int loader_depth;               // LDS-DMA fills in flight per loader wave (1..3; default 1)
+    int nosent;                     // GVC_PERSIST_NOSENT: bit 0 / bit 1: phase D's / phase A's gather polls every plane in every pass (no sentinel round trip)
+    int dbg_layer;                  // GVC_PERSIST_STAMPS: the layer whose phases every workgroup stamps (GVC_PERSIST_STAMP_LAYER, default 2)
     int ln_one_pass;                // experiment: LayerNorm statistics in one pass (GVC_PERSIST_LN_ONE_PASS=1; default 0 = the reference's two-pass form)
     int poll_b, poll_h;             // back-off (s_sleep argument class 0 / 1 / 3) between polls of the q|k|v gather and of the XCD-local h gather
 };
@@ -173,8 +175,10 @@ __device__ __forceinline__ void publish_local(__amdgpu_buffer_rsrc_t rs, int ind
 // j * 128 kPCW, j < NJ.  Sweeps of more than two loads per lane poll a sentinel first (load j = 0 of the last plane) and issue
 // the other loads when its tags have arrived (everything is re-issued if a tag is still old); one- and two-load sweeps re-read
 // everything in every poll pass, which saves a round trip (measured: 612 vs 630 us per step at 110-250 keys).  n is a multiple of 128.
+// gd (diagnostics, GVC_PERSIST_STAMPS): [0] entry, [1] sentinel seen, [2] done (wall clock), [3] sentinel polls, [4] sweep passes
 template <int NJ, int NP>
-__device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code, int sleep = 3) {
+__device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code, int sleep = 3,
+                                       unsigned long long* gd = nullptr, bool no_sentinel = false) {
     if (c.dead || c.wave * 128 >= n) return;         // a wave is all in or all out
     const int t0 = 2 * (c.wave * 64 + c.lane);
     const int voff = (base + t0) * 8;
@@ -182,19 +186,24 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
     unsigned spins = 0;
     pu32x4 v[NJ][NP];
     constexpr bool kSentinel = NJ > 1 || NP > 2;      // one load per lane on <= 2 planes: every poll pass reads everything (one round trip less)
-    while (kSentinel) {
+    unsigned npoll = 0, npass = 0;
+    if (gd) gd[0] = wall_clock64();
+    while (kSentinel && !no_sentinel) {
         v[0][NP - 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (NP - 1) * n * 8, 16);
+        ++npoll;
         if (__all(v[0][NP - 1].y == tag && v[0][NP - 1].w == tag)) break;
         if (spin_fail(c, spins, code, 3)) return;
     }
+    if (gd) { gd[1] = wall_clock64(); gd[3] = npoll; }
     while (true) {
         unsigned bad = 0;
+        ++npass;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if (j == 0 || c.wave * 128 + j * JT < n) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    if (!(kSentinel && j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
+                    if (!(kSentinel && !no_sentinel && j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
             }
         }
 #pragma unroll
@@ -207,6 +216,7 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
         if (!__any(bad != 0u)) break;
         if (spin_fail(c, spins, code, sleep)) return;
     }
+    if (gd) { gd[2] = wall_clock64(); gd[4] = npass; }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         if (j == 0 || c.wave * 128 + j * JT < n) {
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const int base2 = 4 * 5 * (A.n_layer + 2);
         auto stamp_at = [&](int l, int p, int k) {
             if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 4 + k] = wall_clock64();
-            if (stamp0 && l == 2 && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
+            if (stamp0 && l == A.dbg_layer && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
         };
         unsigned fs = 0;                                 // first fill of the current weight segment
         constexpr unsigned nfA = (((3 * ND * D * 4) >> WB) + kPSlot - 1) / kPSlot, nfC = (((ND * D * 4) >> WB) + kPSlot - 1) / kPSlot,
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int nmy = wave < RA ? (RA - wave + kPCW - 1) / kPCW : 0;
                 const int row_g = wg * RA + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.qkv_b[row_g] : 0.f;
-                if (l > 0) gather<NJX, NPX>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l);
+                if (l > 0) gather<NJX, NPX>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l, 3, nullptr, (A.nosent & 2) != 0);
                 cbar(c);
                 stamp_at(l, 0, 0);
                 float val = 0.f;
@@ -892,8 +902,11 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int dwg = XL ? (xx & 7) * 32 + jj : wg;                // XL: hidden units [512 x + 16 j, +16) of XCD x
                 const int row_g = dwg * RD + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.fc_b[row_g] : 0.f;
+                // (diagnostics: wave 0's gather of layer 2 in every workgroup -> [base3 + wg * 8 + ..], and the workgroup's XCD / rank)
+                unsigned long long* gdD = (A.dbg && l == A.dbg_layer && wave == 0) ? A.dbg + base2 + 2 * 5 * kPG + wg * 8 : nullptr;
+                if (gdD && lane == 0) gdD[5] = XL ? (unsigned long long)(((xx & 7) << 8) | jj) : 0xffffull;
                 if (!fused) gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
-                else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
+                else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l, 3, gdD, (A.nosent & 1) != 0);
                 else if (H == 2) gather<NJX, 2>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 else gather<NJX, 1>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 cbar(c);

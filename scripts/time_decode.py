@@ -10,7 +10,7 @@ Tc = int(sys.argv[2]) if len(sys.argv) > 2 else 13
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dims = gcfg.gpt_dims(dict(gcfg.DEFAULT_MODEL_ARGS, gpt_n_heads=int(os.environ.get("HEADS", "4"))))
 w = synth.make_weights(1, synth.gpt_weight_spec(dims), device="cuda")
-eng = GptEngine(dims, max_slots=max(B, 8), max_rows=4096)
+eng = GptEngine(dims, max_slots=max(B, 8), max_rows=4096, weight_dtype=os.environ.get("WEIGHTS", "fp32"))    # WEIGHTS=bf16 / bf16_kv: BASELINE configs[3] storage
 eng.bind(w)
 dev = "cuda"
 cond = synth.uniform(1, "c", (B, 32, 1024), 1.0).to(dev)
