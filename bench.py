@@ -420,12 +420,16 @@ def streams_leg(device, rank, streams=8, weights="bf16_kv", steps=3):
     wb, kvb = (4, 4) if weights == "fp32" else (2, 2 if weights == "bf16_kv" else 4)
     s_mid = wl.P + 1 + n // 2
     by = step_bytes(wl.dims, s_mid, wb, kvb) + (streams - 1) * (2 * wl.dims["n_layer"] * (s_mid + 1) * wl.dims["d_model"]) * kvb
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and weights == "bf16_kv" and streams == 8:     # (the PMC passes of that instantiation: scripts/profile_round.sh)
+        traffic = json.load(open(pmc)).get("k_rows_persist<8,1,1>")
     out = {"workload": f"GenVC_large (:= GenVC_small dims) streaming, 1 s chunks, top_k=1, {streams} concurrent streams on one GPU stepped "
                        f"together, weights/KV {weights}, fp32 accumulation (BASELINE configs[3])",
            "utts_per_s": streams / dt, "rtf_per_stream": dt / SRC_SECONDS, "first_chunk_latency_ms": first_ms,
            "decode_step_us": step_us, "decode_variant": variant,
            "roofline": {"bound": "hbm", "achieved": by / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": by,
+                        "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": by,
                         "kernel": "k_rows_persist<8> (one decode step of 8 streams, sampler + head launches included in the time)"}}
     del wl
     torch.cuda.empty_cache()

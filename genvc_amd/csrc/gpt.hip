@@ -702,7 +702,7 @@ __global__ __launch_bounds__(gvc::kPThreads) void k_xcd_probe(unsigned* hist) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     atomicAdd(hist + (xcc & 7u), 1u);
     atomicAdd(hist + 8, 1u);
-    for (unsigned i = 0; i < (1u << 20); ++i) {
+    for (unsigned i = 0; i < (1u << 16); ++i) {         // (~0.1 s at ~1.5 us per poll; a grid that is dealt one workgroup at a time still ends within half a minute)
         if (__hip_atomic_load(hist + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) return;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -712,16 +712,25 @@ __global__ __launch_bounds__(gvc::kPThreads) void k_xcd_probe(unsigned* hist) {
 // does this device run a 256-workgroup grid of the one-launch step as 8 XCDs x 32 co-resident workgroups?
 static bool xcd_topology_ok(gvc_gpt* c) {
     if (!c->arch_xcc) return false;
+    // GVC_PERSIST_XCD_PROBE=0: trust the part (8 XCDs x 32) without running the probe -- for `rocprofv3 --pmc` runs, under which the probe grid
+    // (workgroups waiting for each other) was seen never to complete while the one-launch steps themselves run normally
+    static const int probe = getenv("GVC_PERSIST_XCD_PROBE") ? atoi(getenv("GVC_PERSIST_XCD_PROBE")) : 1;
+    if (!probe) return c->n_cu == kPG;
     unsigned* hist = nullptr;
     unsigned h[10] = {0};
     bool ok = hipMalloc((void**)&hist, sizeof(h)) == hipSuccess && hipMemset(hist, 0, sizeof(h)) == hipSuccess &&
+              hipDeviceSynchronize() == hipSuccess &&
               hipFuncSetAttribute((const void*)k_xcd_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->p_lds) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_xcd_probe, dim3(kPG), dim3(kPThreads), c->p_lds, 0, hist);
-        ok = hipGetLastError() == hipSuccess && hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        // (on the context's own non-blocking stream: a launch on the legacy default stream drags every other stream's pending work in)
+        hipLaunchKernelGGL(k_xcd_probe, dim3(kPG), dim3(kPThreads), c->p_lds, c->cap_stream, hist);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->cap_stream) == hipSuccess &&
+             hipMemcpy(h, hist, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
     }
     if (hist) (void)hipFree(hist);
     (void)hipGetLastError();
+    if (getenv("GVC_PERSIST_PROBE_DEBUG"))
+        fprintf(stderr, "xcd probe: ok %d, per-XCD %u %u %u %u %u %u %u %u, arrived %u, gave up %u\n", (int)ok, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
     if (!ok || h[9] != 0 || h[8] != (unsigned)kPG) return false;
     for (int x = 0; x < 8; ++x)
         if (h[x] != (unsigned)kPG / 8) return false;
@@ -794,6 +803,9 @@ static int persist_prepare(gvc_gpt* c) {
         if (dev) (void)hipFree(dev);
         return unavailable();
     }
+    // the memsets above went to the legacy default stream; the caller's stream may be a non-blocking one (no implicit ordering with it), so
+    // the first launch must not be enqueued before they have landed (seen as a hang of the first step under `rocprofv3 --pmc`)
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(dev); return unavailable(); }
     c->p_layers = dev;
     return GVC_OK;
 }

@@ -334,3 +334,32 @@ def test_xcd_probe_gates_the_xcd_local_hand_off():
         assert eng.decode_variant() == 3
         assert torch.equal(toks.long(), ref_t[:, :toks.shape[1]])
     eng.close()
+
+
+def test_perceiver_batches_beyond_one_skinny_group_and_short_contexts_vs_oracle():
+    """The round-5 Perceiver (csrc/perceiver.hip: latents fragment-major on the skinny GEMM, context keys / values of all layers in one
+    GEMM, graph replay per (B, F)) outside the fixture's two shapes: six batch elements (the latent path takes them in groups of four:
+    128 rows per skinny GEMM), different contexts per element, a context shorter than one key tile and one that is not a multiple of
+    16, a repeated call (graph replay) and a rebind -- against the oracle's PerceiverResampler restatement
+    (/root/reference/layers/perceiver_encoder.py:265-319, pinned by tests/golden/perceiver.npz)."""
+    from genvc_amd.engine import PerceiverEngine
+    from oracle import genvc_oracle as O
+    d = 256
+    pre = "conditioning_perceiver."
+    w = synth.make_weights(3, synth.perceiver_weight_spec(d, prefix=pre), device=DEV)
+    eng = PerceiverEngine(dim=d, depth=4, dim_context=80, num_latents=32, dim_head=64, heads=8, ff_mult=4, max_batch=8, max_frames=600)
+    eng.bind(w, prefix=pre)
+    wc = {k: v.cpu() for k, v in w.items()}
+    for B, Fr in ((6, 100), (1, 7), (3, 45), (6, 100)):
+        x = synth.uniform(5, f"ctx_{B}_{Fr}", (B, Fr, 80), 1.0)
+        y = eng.forward(x.to(DEV).contiguous()).cpu()
+        ref = O.perceiver_forward(wc, x, prefix=pre)
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=5e-5, err_msg=f"B={B} F={Fr}")
+    # rebind other weights: the fragment-major / interleaved copies and the captured graphs must follow
+    w2 = synth.make_weights(4, synth.perceiver_weight_spec(d, prefix=pre), device=DEV)
+    eng.bind(w2, prefix=pre)
+    x = synth.uniform(6, "ctx_rebind", (2, 100, 80), 1.0)
+    y = eng.forward(x.to(DEV).contiguous()).cpu()
+    ref = O.perceiver_forward({k: v.cpu() for k, v in w2.items()}, x, prefix=pre)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=5e-5)
+    eng.close()
