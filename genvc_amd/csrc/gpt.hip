@@ -712,14 +712,9 @@ __global__ __launch_bounds__(gvc::kPThreads) void k_xcd_probe(unsigned* hist) {
 // does this device run a 256-workgroup grid of the one-launch step as 8 XCDs x 32 co-resident workgroups?
 static bool xcd_topology_ok(gvc_gpt* c) {
     if (!c->arch_xcc) return false;
-    // GVC_PERSIST_XCD_PROBE=0: trust the part (8 XCDs x 32) without running the probe -- for `rocprofv3 --pmc` runs, under which the probe grid
-    // (workgroups waiting for each other) was seen never to complete while the one-launch steps themselves run normally
-    static const int probe = getenv("GVC_PERSIST_XCD_PROBE") ? atoi(getenv("GVC_PERSIST_XCD_PROBE")) : 1;
-    if (!probe) return c->n_cu == kPG;
     unsigned* hist = nullptr;
     unsigned h[10] = {0};
-    bool ok = hipMalloc((void**)&hist, sizeof(h)) == hipSuccess && hipMemset(hist, 0, sizeof(h)) == hipSuccess &&
-              hipDeviceSynchronize() == hipSuccess &&
+    bool ok = hipMalloc((void**)&hist, sizeof(h)) == hipSuccess && hipMemsetAsync(hist, 0, sizeof(h), c->cap_stream) == hipSuccess &&
               hipFuncSetAttribute((const void*)k_xcd_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->p_lds) == hipSuccess;
     if (ok) {
         // (on the context's own non-blocking stream: a launch on the legacy default stream drags every other stream's pending work in)
@@ -775,6 +770,10 @@ static int persist_prepare(gvc_gpt* c) {
         const size_t nb = (size_t)(20 * (L + 2) + 2 * 5 * kPG + 8 * kPG) * sizeof(unsigned long long);
         if (hipMalloc((void**)&c->p_dbg, nb) != hipSuccess || hipMemset(c->p_dbg, 0, nb) != hipSuccess) return unavailable();
     }
+    // the memsets above went to the legacy default stream; the caller's stream may be a non-blocking one (no implicit ordering with it): they
+    // must have landed before the first launch is enqueued.  (Device-wide sync HERE, before the context's own stream has run anything: under
+    // `rocprofv3 --pmc` a device-wide sync behind the probe launch on that stream -- or the probe on the default stream -- never returned.)
+    if (hipDeviceSynchronize() != hipSuccess) return unavailable();
     const int ng_hd = kPCW * 256;                       // lane-group states of the attention phase: [kPCW * 64 / (hd / 4)][hd]
     c->p_hvec = 4 * d > d + ng_hd ? 4 * d : d + ng_hd;
     c->p_ascr = 3 * c->hd + 64;
@@ -803,9 +802,6 @@ static int persist_prepare(gvc_gpt* c) {
         if (dev) (void)hipFree(dev);
         return unavailable();
     }
-    // the memsets above went to the legacy default stream; the caller's stream may be a non-blocking one (no implicit ordering with it), so
-    // the first launch must not be enqueued before they have landed (seen as a hang of the first step under `rocprofv3 --pmc`)
-    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(dev); return unavailable(); }
     c->p_layers = dev;
     return GVC_OK;
 }
