@@ -355,6 +355,10 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
         const long long key = (long long)B * 100000 + F;
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
+            if (c->graphs.size() >= 32) {          // a long-running caller with ever new reference lengths: keep the cache bounded
+                for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
+                c->graphs.clear();
+            }
             hipGraph_t graph = nullptr;
             GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
             rc = perc_launch(c, B, F, c->cap_stream, c->side_stream);

@@ -363,3 +363,54 @@ def test_perceiver_batches_beyond_one_skinny_group_and_short_contexts_vs_oracle(
     ref = O.perceiver_forward({k: v.cpu() for k, v in w2.items()}, x, prefix=pre)
     np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=5e-5)
     eng.close()
+
+
+def test_stream_sessions_recover_when_the_time_out_surfaces_at_a_later_call(monkeypatch):
+    """a hand-off time-out does not only surface at the health check behind the decode call -- the entry check of
+    the NEXT library call (this step's prefill of a new segment, the next step's generate) reports what the previous call left behind.
+    Injected: the prefill of a stream's second segment and, later, a generate call raise the library's time-out error once each.
+    StreamSessions.step() must put every affected stream back to the start of its segment (the one that was popped but not yet
+    decoding too), emit nothing twice, and every stream must still end with its solo conversion's tokens and waveform."""
+    from genvc_amd._lib import GenvcHipError
+    from genvc_amd.inference.inference_utils import segments, synthesize_utt_streaming
+    from genvc_amd.streaming import StreamSessions
+    m = _wide_tiny_model()
+    refs = [synth.synth_audio(60 + i, "ref", 72000) for i in range(2)]
+    srcs = [synth.synth_audio(80 + i, "src", 48000) for i in range(2)]
+    solo = [synthesize_utt_streaming(m, srcs[i], refs[i], seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True) for i in range(2)]
+    ss = StreamSessions(m, max_sessions=4, group=8)
+    eng = ss.eng
+    real_prefill, real_generate = eng.prefill, eng.generate
+    calls = {"prefill": 0, "generate": 0}
+
+    def prefill(*a, **k):
+        calls["prefill"] += 1
+        if calls["prefill"] == 3:
+            raise GenvcHipError("prefill: injected -- an in-kernel hand-off of a one-launch decode step timed out")
+        return real_prefill(*a, **k)
+
+    def generate(*a, **k):
+        calls["generate"] += 1
+        if calls["generate"] == 9:
+            raise GenvcHipError("generate: injected -- an in-kernel hand-off of a one-launch decode step timed out")
+        return real_generate(*a, **k)
+    eng.prefill, eng.generate = prefill, generate
+    sids = [ss.open(r) for r in refs]
+    for i, sid in enumerate(sids):
+        for sg in segments(srcs[i], 16000, 5120):
+            ss.push(sid, sg)
+    wavs, steps = {}, 0
+    while not ss.idle():
+        for sid, chunks in ss.step().items():
+            wavs.setdefault(sid, []).extend(chunks)
+        steps += 1
+        assert steps < 200
+    assert ss.recoveries == 2
+    for i, sid in enumerate(sids):
+        mine = torch.cat(ss.close(sid), 1)[0].cpu()
+        assert torch.equal(mine, torch.cat(solo[i]["tokens"], 1)[0].cpu()), f"stream {i}: tokens differ after the recoveries"
+        w = torch.cat(wavs[sid], -1)
+        assert w.shape == solo[i]["wav"].shape
+        np.testing.assert_allclose(w.cpu().numpy(), solo[i]["wav"].cpu().numpy(), atol=2e-4)
+    del m
+    torch.cuda.empty_cache()
