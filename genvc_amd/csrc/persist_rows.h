@@ -168,7 +168,11 @@ __device__ __forceinline__ pu32x4 as_u4(float4 v) {
 // 16-byte write-through store of a hand-off element and the poison of the same element in the other parity
 __device__ __forceinline__ void rpublish(__amdgpu_buffer_rsrc_t rs, int off_cur, int off_other, float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(as_u4(v), rs, off_cur, 0, 16);
-    const pu32x4 p = {kRPoison, kRPoison, kRPoison, kRPoison};
+    // the poison pattern is re-materialised at every use (-1 is an inline constant): as a plain constant the compiler keeps the vector live across
+    // the whole layer loop, and in the 16-row instantiations (168 VGPRs) spills it -- a scratch reload and an `s_waitcnt vmcnt` behind every publish
+    unsigned pv;
+    asm volatile("v_mov_b32 %0, -1" : "=v"(pv));
+    const pu32x4 p = {pv, pv, pv, pv};
     __builtin_amdgcn_raw_buffer_store_b128(p, rs, off_other, 0, 16);
 }
 
