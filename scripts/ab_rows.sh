@@ -3,6 +3,7 @@
 # settings of an environment knob, against genvc_amd/lib/libgenvc_hip_r05base.so (the round-4 kernels)
 # usage: scripts/ab_rows.sh OUTDIR [KNOB "v1 v2 ..."]
 out=${1:-gpurun_out/ab}; knob=${2:-GVC_NONE}; vals=${3:-x}; mkdir -p $out
+[ -f genvc_amd/lib/libgenvc_hip_r05base.so ] || { echo "build the round-4 sources (git checkout 5b11e86 -- genvc_amd/csrc; python -m genvc_amd.build) and keep the library as genvc_amd/lib/libgenvc_hip_r05base.so first"; exit 1; }
 run() { python scripts/time_decode.py $1 $2 $3 2>&1 | grep "us/step (" | tail -1 | sed -E "s/.*decode ([0-9.]+) us.*/\1/"; }
 for rep in 1 2 3; do
   for cfg in base $vals; do
