@@ -67,6 +67,7 @@ _SIGNATURES = {
     "gvc_gpt_health": (C.c_int, [_P]),
     "gvc_gpt_warmup": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "gvc_gpt_lazy_inits": (C.c_longlong, [_P]),
+    "gvc_gpt_rearm": (C.c_int, [_P]),
     "gvc_gpt_time_kernel": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, c_f32p, c_i32p, _P]),
     "gvc_gemm_probe": (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, _P]),
     "gvc_perceiver_create": (C.c_int, [C.POINTER(PerceiverDims), C.POINTER(_P)]),

@@ -266,6 +266,7 @@ struct gvc_gpt {
     size_t p_lds = 0;
     int last_variant = 0;             // decode variant of the last gvc_gpt_generate call (gvc_gpt_decode_variant)
     int fallbacks = 0;                // hand-off timeouts that switched the one-launch steps off (gvc_gpt_health)
+    int persist_cfg = 1;              // what GVC_PERSIST allowed at create (gvc_gpt_rearm restores it)
     // one-launch block stack for 2..16 rows (persist_rows.h): batched decode steps, cached chunk prefills
     int persist_rows = 1;             // GVC_PERSIST_ROWS=0: those calls keep the launch-per-phase rows path
     int persist_rows_min = 2;         // GVC_PERSIST_ROWS_MIN: smallest row count served
@@ -392,6 +393,7 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     *c->seam_err_host = 0;
     GVC_CHECK_HIP(hipHostGetDevicePointer((void**)&c->seam_err_dev, c->seam_err_host, 0));
     if (getenv("GVC_PERSIST")) c->persist = atoi(getenv("GVC_PERSIST"));
+    c->persist_cfg = c->persist;
     if (getenv("GVC_PERSIST_ROWS")) c->persist_rows = atoi(getenv("GVC_PERSIST_ROWS"));
     if (getenv("GVC_PERSIST_ROWS_MIN")) c->persist_rows_min = std::max(2, atoi(getenv("GVC_PERSIST_ROWS_MIN")));
     if (getenv("GVC_ROWS_PERSIST_SPLIT")) sscanf(getenv("GVC_ROWS_PERSIST_SPLIT"), "%d,%d", &c->r_split1, &c->r_split2);
@@ -1475,6 +1477,24 @@ extern "C" int gvc_gpt_warmup(gvc_gpt* c, int32_t B, int32_t max_keys, int32_t t
 }
 
 extern "C" long long gvc_gpt_lazy_inits(gvc_gpt* c) { return c ? c->lazy_inits : 0; }
+
+// After a hand-off time-out the context runs on the launch-per-phase paths.  That is the right answer while another context holds CUs, and
+// the wrong one for the rest of a server's life: when the caller knows the GPU is its own again (a quiet moment, the other process gone) it
+// re-arms the one-launch steps here.  Synchronises the device, drops the captured step graphs (they hold the fallback launches) and resets
+// the hand-off state; a later time-out simply falls back again.  Pending errors are reported first, exactly as by gvc_gpt_health.
+extern "C" int gvc_gpt_rearm(gvc_gpt* c) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (c->persist == c->persist_cfg) return GVC_OK;
+    GVC_CHECK_HIP(hipDeviceSynchronize());
+    for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
+    c->graphs.clear();
+    if (c->r_bufs) GVC_CHECK_HIP(hipMemset(c->r_bufs, 0xff, rows_buf_bytes()));
+    if (c->p_epoch) GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned)));
+    GVC_CHECK_HIP(hipDeviceSynchronize());
+    c->persist = c->persist_cfg;
+    return GVC_OK;
+}
 
 extern "C" int gvc_gpt_generate(gvc_gpt* c, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
                                 int32_t* ids_len, int32_t* finished, const gvc_sample_params* p, int32_t i0,

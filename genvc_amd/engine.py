@@ -144,6 +144,10 @@ class GptEngine:
         """allocations / device syncs / graph captures done inside data-path calls so far (include/genvc_hip.h: gvc_gpt_lazy_inits)"""
         return int(lib().gvc_gpt_lazy_inits(self._h))
 
+    def rearm(self):
+        """back to the one-launch steps after a time-out fallback, when the GPU is the caller's own again (include/genvc_hip.h: gvc_gpt_rearm)"""
+        check(lib().gvc_gpt_rearm(self._h), "rearm")
+
     def rows_step_launches(self):
         """one-launch rows steps issued so far (include/genvc_hip.h: gvc_gpt_rows_step_launches)"""
         return int(lib().gvc_gpt_rows_step_launches(self._h))

@@ -63,6 +63,7 @@ class StreamSessions:
         self.params = sample_params(samp, g.num_audio_tokens, g.stop_audio_token, 0)
         self.calls = 0
         self.recoveries = 0          # decode calls dropped and re-run after a hand-off time-out (gvc_gpt_health)
+        self._rearm = False          # a recovery happened: re-arm the one-launch steps at the next idle moment
         self.stop = g.stop_audio_token
         # per-slot history of input ids (fake prefix + generated), as wide as the longest run
         self.width = 32 + g.max_text_tokens + 2 + 1 + self.max_new + 8
@@ -92,7 +93,17 @@ class StreamSessions:
         return s.tokens
 
     def idle(self):
-        return all(not s.decoding and not s.queue for s in self.sessions.values())
+        idle = all(not s.decoding and not s.queue for s in self.sessions.values())
+        if idle and self._rearm:
+            # a quiet moment after a time-out recovery: nothing of ours is in flight, try the one-launch steps again (if the other context
+            # still holds CUs the next decode call times out once more and is recovered the same way)
+            self._rearm = False
+            try:
+                torch.cuda.synchronize()
+                self.eng.rearm()
+            except GenvcHipError:
+                pass
+        return idle
 
     @torch.inference_mode()
     def segment_features(self, ss, wav):
@@ -134,6 +145,7 @@ class StreamSessions:
 
     def _recover(self):
         self.recoveries += 1
+        self._rearm = True
         redo = []
         for s in self.sessions.values():
             if s.decoding:

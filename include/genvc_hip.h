@@ -196,6 +196,10 @@ int gvc_gpt_warmup(gvc_gpt* ctx, int32_t B, int32_t max_keys, int32_t top_k);
  * of a path that gvc_gpt_warmup had not prepared; a rebind after the weight pack was built; the fallback after a hand-off
  * time-out).  gvc_gpt_warmup's own work does not count.  Tests assert it stays put across warmed-up calls. */
 long long gvc_gpt_lazy_inits(gvc_gpt* ctx);
+/* Re-arm the one-launch steps after a hand-off time-out has switched the context to the launch-per-phase paths (gvc_gpt_health): to be called
+ * when the caller knows the GPU is its own again (no reference counterpart).  Reports pending errors like gvc_gpt_health; synchronises the
+ * device, drops the captured step graphs and resets the hand-off state.  A later time-out falls back again. */
+int gvc_gpt_rearm(gvc_gpt* ctx);
 
 /* Measurement hook used by bench.py (not a reference interface): launches ONLY one kernel class of the
  * decode step (0 c_attn GEMV, 1 attention, 2 attn c_proj GEMV, 3 mlp c_fc GEMV, 4 mlp c_proj GEMV, 5 head
