@@ -429,6 +429,317 @@ def make_chain(GPT, DiscreteVAE, seed=1, src_seed=402, ref_seed=100, n_chunks=3,
     print(f"chain_full: {tok.shape[1]} tokens in {n_chunks} chunks, min margin {mg.min():.3e}, wav {wav.shape[0]} samples, rms {np.sqrt((wav ** 2).mean()):.4f}")
 
 
+# ---------------------------------------------------------------------------
+# round 6: the reference's OWN generation loop and harness functions, executed (not restated)
+# ---------------------------------------------------------------------------
+
+def import_stream_generator():
+    """/root/reference/layers/stream_generator.py imports four beam-search names that transformers 5 removed (:13-23) and
+    `SampleOutput` (:24).  None of them is reached with num_beams = 1: empty stand-in classes on the `transformers` module let the
+    file import, and `NewGenerationMixin.sample_stream` (:645-881) -- the loop GPT.get_generator / GPT.generate end in -- runs as is."""
+    import transformers
+    import transformers.generation.utils as gu
+    for n in ("BeamSearchScorer", "ConstrainedBeamSearchScorer", "DisjunctiveConstraint", "PhrasalConstraint"):
+        if not hasattr(transformers, n):
+            setattr(transformers, n, type(n, (), {}))
+    if not hasattr(gu, "SampleOutput"):
+        gu.SampleOutput = object
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from layers import stream_generator as SG
+    return SG
+
+
+class _StoppingCriteria433(list):
+    """transformers 4.33 StoppingCriteriaList.__call__: `any(criteria(input_ids, scores) for criteria in self)`, ONE bool for the
+    batch (transformers 5 returns a per-row tensor, which `if ... or stopping_criteria(...)` at stream_generator.py:877 cannot take)."""
+    def __call__(self, input_ids, scores, **kw):
+        return any(bool(torch.as_tensor(c(input_ids, scores)).all()) for c in self)
+
+
+class _MarginTap:
+    """a pass-through logits processor behind the repetition penalty: records the top-1 / top-2 gap of the scores the draw sees"""
+    def __init__(self):
+        self.gaps = []
+
+    def __call__(self, input_ids, scores):
+        t2 = torch.topk(scores, 2, dim=-1)[0]
+        self.gaps.append((t2[:, 0] - t2[:, 1]).numpy().copy())
+        return scores
+
+
+def arm_reference_generation(g, SG):
+    """Give the reference GPT2InferenceModel what `PreTrainedModel.generate_stream = NewGenerationMixin.generate`
+    (stream_generator.py:884-886) gave it under transformers 4.33.  The dispatcher `NewGenerationMixin.generate` (:46-640) is 600 lines
+    against 4.33's private GenerationMixin API (`_validate_model_class`, `_get_logits_warper`, ...: gone in 5.x), so the part of it the
+    reference's call reaches (do_sample=True, num_beams=1: :186-193 attention mask of ones since pad == eos, :181-182 use_cache,
+    :337-347 `_get_logits_processor` -> RepetitionPenalty, :437 `_get_logits_warper` -> Temperature, TopK, TopP in that order with
+    min_tokens_to_keep = 1, :345 MaxLengthCriteria(max_length), :449-461 the call) is this shim; the LOOP it calls is the reference's
+    own `sample_stream`, unmodified, bound to the reference model.  `generate` (non-streaming; 4.33's `GenerationMixin.sample`, the
+    function sample_stream was adapted from: same body with `yield` replaced by accumulation) drains the same loop and returns
+    cat(input_ids, tokens) like `sample` does."""
+    import types as _t
+    from transformers import GenerationConfig, GenerationMixin, LogitsProcessorList
+    from transformers.generation.logits_process import (
+        RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper)
+    from transformers.generation.stopping_criteria import MaxLengthCriteria
+    gi = g.gpt_inference
+    gi.generation_config = GenerationConfig()
+    gi._update_model_kwargs_for_generation = _t.MethodType(GenerationMixin._update_model_kwargs_for_generation, gi)
+    tap = _MarginTap()
+
+    def stream(inputs, bos_token_id=None, pad_token_id=None, eos_token_id=None, max_length=None, do_stream=False,
+               do_sample=True, top_p=1.0, top_k=50, temperature=1.0, length_penalty=1.0, repetition_penalty=1.0, num_beams=1,
+               num_return_sequences=1, output_attentions=False, output_hidden_states=False):
+        assert do_sample and num_beams == 1 and num_return_sequences == 1
+        procs = LogitsProcessorList(([RepetitionPenaltyLogitsProcessor(repetition_penalty)] if repetition_penalty != 1.0 else []) + [tap])
+        warp = LogitsProcessorList(
+            ([TemperatureLogitsWarper(temperature)] if temperature != 1.0 else [])
+            + ([TopKLogitsWarper(top_k, min_tokens_to_keep=1)] if top_k else [])
+            + ([TopPLogitsWarper(top_p, min_tokens_to_keep=1)] if top_p < 1.0 else []))
+        return SG.NewGenerationMixin.sample_stream(
+            gi, inputs, logits_processor=procs, logits_warper=warp,
+            stopping_criteria=_StoppingCriteria433([MaxLengthCriteria(max_length=max_length)]),
+            pad_token_id=pad_token_id, eos_token_id=eos_token_id, output_attentions=output_attentions,
+            output_hidden_states=True, attention_mask=torch.ones_like(inputs), use_cache=True)
+
+    def generate(inputs, **kw):
+        toks = [t for t, _ in stream(inputs, **kw)]
+        return torch.cat([inputs, torch.stack(toks, 1)], dim=-1)
+
+    gi.generate_stream = stream
+    gi.generate = generate
+    return tap
+
+
+@torch.inference_mode()
+def make_stream_loop(GPT, seed=29):
+    """tests/golden/stream_loop.npz: `NewGenerationMixin.sample_stream` itself (stream_generator.py:645-881) driven through the reference's
+    `GPT.get_generator` (gpt.py:610-621) on the reference GPT2InferenceModel: (a) B = 3 with a raised stop-token bias -- rows end at
+    different steps, finished rows yield the pad, the loop ends with the last row, the EOS-step pair is yielded; (b) a run that ends on
+    `max_length` (`max_gen_mel_tokens` lowered on the reference object); (c) `GPT.generate` (gpt.py:594-608) for the same inputs as (b)."""
+    SG = import_stream_generator()
+    model_args = gcfg.TINY_MODEL_ARGS
+    dims = gcfg.gpt_dims(model_args)
+    w = synth.make_weights(seed, synth.gpt_weight_spec(dims))
+    kw = dict(top_p=0.85, top_k=1, temperature=0.85, length_penalty=1.0, repetition_penalty=2.0, do_sample=True, num_beams=1,
+              num_return_sequences=1, output_attentions=False, output_hidden_states=True)
+
+    def run(g, tap, cond, codes):
+        tap.gaps.clear()
+        fake = g.compute_embeddings(cond, codes)
+        pairs = list(g.get_generator(fake_inputs=fake, **kw))
+        toks = torch.stack([p[0] for p in pairs], 1)
+        lats = torch.stack([p[1] for p in pairs], 1)
+        return toks.numpy(), lats.numpy(), np.stack(tap.gaps, 1)
+
+    out = dict(seed=seed)
+    # (a) ragged EOS at B = 3
+    found = False
+    for bias in np.arange(0.2, 3.0, 0.05):
+        w["mel_head.bias"][1025] = float(bias)
+        g = build_ref_gpt(GPT, model_args, w)
+        tap = arm_reference_generation(g, SG)
+        for in_seed in range(seed * 100, seed * 100 + 6):
+            cond, codes = gpt_inputs(in_seed, dims, 3, 11)
+            toks, lats, gaps = run(g, tap, cond, codes)
+            ends = [int((toks[b] == 1025).argmax()) if (toks[b] == 1025).any() else -1 for b in range(3)]
+            live = np.concatenate([gaps[b, :ends[b] + 1] for b in range(3)]) if min(ends) >= 0 else np.zeros(1)
+            if min(ends) >= 3 and len(set(ends)) == 3 and toks.shape[1] < 60 and live.min() > 2e-3:
+                found = True
+                break
+        if found:
+            break
+    assert found, "no ragged-EOS case found"
+    out.update(eos_bias=float(bias), eos_in_seed=in_seed, eos_tokens=toks, eos_latents_slice=lats[:, :, :32], eos_margins=gaps,
+               eos_ends=np.array(ends))
+    print(f"stream_loop (a): bias {bias:.2f}, in_seed {in_seed}, ends {ends}, {toks.shape[1]} yields, min live margin {live.min():.2e}")
+    # (b) + (c): ends on max_length
+    w["mel_head.bias"][1025] = 0.0
+    g = build_ref_gpt(GPT, model_args, w)
+    tap = arm_reference_generation(g, SG)
+    g.max_gen_mel_tokens = 21
+    for in_seed in range(seed * 100 + 50, seed * 100 + 80):
+        cond, codes = gpt_inputs(in_seed, dims, 2, 13)
+        toks, lats, gaps = run(g, tap, cond, codes)
+        if gaps.min() > 2e-3 and not (toks == 1025).any():
+            break
+    else:
+        raise RuntimeError("no max_length case passed the margin screen")
+    gen = g.generate(cond, codes, **{k: v for k, v in kw.items() if k not in ("num_return_sequences", "output_hidden_states")})
+    assert toks.shape[1] == 21 and torch.equal(gen, torch.from_numpy(toks))
+    out.update(max_in_seed=in_seed, max_new=21, max_tokens=toks, max_latents_slice=lats[:, :, :32], max_margins=gaps,
+               generate_tokens=gen.numpy())
+    print(f"stream_loop (b): in_seed {in_seed}, {toks.shape[1]} yields (max_length), min margin {gaps.min():.2e}; generate() equal")
+    np.savez_compressed(os.path.join(GOLD, "stream_loop.npz"), **out)
+
+
+class _Duck:
+    """attribute bag standing in for the reference's HiFiGANTrainer object"""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def build_reference_model(GPT, DiscreteVAE, cfg, seed, max_new, stop_bias=None):
+    """A model object with the attributes the reference's harness functions touch (inference/inference_utils.py:23-217), every one of
+    them the REFERENCE's own class on the synthetic weights model_init_synthetic(cfg, seed) loads: `.gpt` = reference GPT (with the
+    reference's sample_stream behind get_generator / generate), `.content_dvae` = reference DiscreteVAE, `.hifigan` = reference HiFiGAN,
+    `.get_gpt_cond_latents` = trainers/hifigan_trainer.py:438-455 restated on the reference's `GPT.get_style_emb` (the trainer class
+    pulls the whole training stack in) over the oracle's mel (torchaudio absent), `.content_extractor` = HuggingFace HubertModel +
+    final_proj (fairseq absent); a segment with all-zero frames -- the zero-padded tail, content_processor.py:24 -- goes through the
+    oracle's masked forward, the one stage nothing here can pin."""
+    from oracle import genvc_oracle as O
+    from genvc_amd.utils import DEFAULT_MEL_NORM_FILE, load_mel_norms
+    stub = types.ModuleType("nnAudio"); stub.features = types.ModuleType("nnAudio.features")
+    sys.modules["nnAudio"], sys.modules["nnAudio.features"] = stub, stub.features
+    from layers.hifigan import HiFiGAN
+    SG = import_stream_generator()
+    dims = gcfg.gpt_dims(cfg.model_args)
+    gw = synth.make_weights(seed, synth.gpt_weight_spec(dims))
+    if stop_bias is not None:
+        gw["mel_head.bias"][1025] = float(stop_bias)
+    g = build_ref_gpt(GPT, cfg.model_args, gw)
+    tap = arm_reference_generation(g, SG)
+    g.max_gen_mel_tokens = max_new
+    c = cfg.content_dvae_config
+    dv = DiscreteVAE(channels=c["num_channels"], normalization=None, positional_dims=1, num_tokens=c["num_tokens"],
+                     codebook_dim=c["codebook_dim"], hidden_dim=c["hidden_dim"], num_resnet_blocks=c["num_resnet_blocks"],
+                     kernel_size=c["kernel_size"], num_layers=c["num_layers"], use_transposed_convs=False)
+    missing, unexpected = dv.load_state_dict(synth.make_weights(seed, synth.dvae_weight_spec(c)), strict=False)
+    assert not unexpected
+    dv.eval()
+    hcfg = dict(cfg.hubert_config)
+    hw = synth.make_weights(seed, synth.hubert_weight_spec(hcfg))
+    hub = build_hf_hubert(hcfg, hw)
+    v = cfg.vocoder_config
+    voc = HiFiGAN(v["input_feat_dim"], v["upsample_initial_channel"], v["resblock_kernel_sizes"], v["resblock_dilation_sizes"],
+                  v["upsample_rates"], v["upsample_kernel_sizes"], resblock_type="2")
+    voc.load_state_dict(synth.make_weights(seed, synth.hifigan_weight_spec(v)), strict=True)
+    voc.eval()
+    norms = torch.from_numpy(load_mel_norms(DEFAULT_MEL_NORM_FILE))
+    log = dict(codes=[], masked_segments=0)
+
+    def extract_content_features(wav):
+        x = hub(wav).last_hidden_state
+        n_frames = x.shape[1]
+        if bool(O.hubert_frame_padding_mask(wav, n_frames).any()):
+            log["masked_segments"] += 1
+            return O.hubert_extract_features(hw, hcfg, wav)
+        return torch.nn.functional.linear(x, hw["final_proj.weight"], hw["final_proj.bias"])
+
+    def get_codebook_indices(feat):
+        codes = dv.get_codebook_indices(feat)
+        log["codes"].append(codes.numpy().copy())
+        return codes
+
+    def get_gpt_cond_latents(audio, sr, length=30, chunk_length=6):
+        if sr != 24000:
+            raise NotImplementedError
+        audio = audio[:, :24000 * length]
+        embs = []
+        for i in range(0, audio.shape[1], 24000 * chunk_length):
+            chunk = audio[:, i:i + 24000 * chunk_length]
+            if chunk.size(-1) < 24000 * 0.33:
+                continue
+            embs.append(g.get_style_emb(O.mel_spectrogram(chunk, norms), None))
+        return torch.stack(embs).mean(dim=0).transpose(1, 2)
+
+    sampling = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
+    m = _Duck(gpt=g, content_dvae=_Duck(get_codebook_indices=get_codebook_indices), hifigan=voc,
+              content_extractor=_Duck(extract_content_features=extract_content_features),
+              get_gpt_cond_latents=get_gpt_cond_latents, content_sample_rate=16000, device=torch.device("cpu"),
+              hifigan_scale_factor=4.0,
+              config=_Duck(audio=_Duck(sample_rate=24000), model_args=_Duck(gpt_code_stride_len=1024), **sampling))
+    return m, tap, log
+
+
+@torch.inference_mode()
+def make_harness(GPT, DiscreteVAE, only=("tiny", "full")):
+    """tests/golden/harness_{tiny,full}.npz: the reference's UNCHANGED `synthesize_utt_streaming(seg_len=1.0, stream_chunk_size=8)`
+    (inference/inference_utils.py:135-217) and `synthesize_utt(seg_len=1.0)` (:23-89) called on `build_reference_model`.  Source 2.2 s
+    = 1 s + 1 s + a 0.2 s tail the harness zero-pads to 0.32 s (:43-50).  Two endings: `max_length` (26 yields: groups 8, 8, 8, 2) and a
+    raised stop bias (the EOS-step pair is streamed, :189-196; `synthesize_utt` strips the stop token, :68).  The streamed (token, latent)
+    pairs are taken from a tap on the generator, the group boundaries from the lengths the reference's `hifigan.forward` is called with."""
+    import contextlib
+    import io
+    sys.path.insert(0, "/root/reference")
+    from inference import inference_utils as RIU
+    for tag in only:
+        tiny = tag == "tiny"
+        cfg = gcfg.default_config(tiny=tiny)
+        seed = 3 if tiny else 1
+        out = dict(seed=seed, max_new=26)
+        ref = synth.synth_audio(100, "ref", 72000)
+        cases = [("max", None)] + ([("eos", "search")] if tiny else [])
+        for case, bias in cases:
+            biases = [None] if bias is None else list(np.arange(0.3, 3.0, 0.05))
+            done = False
+            for b in biases:
+                m, tap, log = build_reference_model(GPT, DiscreteVAE, cfg, seed, 26, stop_bias=b)
+                vo_lens, pairs = [], []
+                voc_forward = m.hifigan.forward
+
+                def forward(x, _f=voc_forward):
+                    vo_lens.append(int(x.shape[-1]) // 4)
+                    return _f(x)
+                m.hifigan.forward = forward
+                get_gen = m.gpt.get_generator
+
+                def tapped(*a, _g=get_gen, **k):
+                    for t, lat in _g(*a, **k):
+                        pairs.append((t.numpy().copy(), lat.numpy().copy()))
+                        yield t, lat
+                m.gpt.get_generator = tapped
+                for src_seed in range(500, 500 + (12 if tiny else 4)):
+                    src = synth.synth_audio(src_seed, "src", 35200)
+                    tap.gaps.clear(); vo_lens.clear(); pairs.clear(); log["codes"].clear(); log["masked_segments"] = 0
+                    try:
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            wav_s = RIU.synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8)
+                    except (RuntimeError, ValueError) as e:   # a segment whose yields are a multiple of 8: torch.cat([]) at :196 raises (DESIGN.md, quirk 16)
+                        print(f"  harness_{tag}/{case}: src seed {src_seed} bias {b}: reference raised {str(e)[:60]!r}")
+                        continue
+                    toks = np.concatenate([p[0] for p in pairs])
+                    gaps = np.concatenate(tap.gaps)
+                    n_stream = len(pairs)
+                    ok = gaps[:n_stream].min() > 2e-3
+                    if case == "eos":
+                        per_seg = np.split(toks, np.nonzero(toks == 1025)[0] + 1)[:-1]
+                        ok = ok and len(per_seg) == 3 and all(3 <= len(s) < 26 for s in per_seg) and int((toks == 1025).sum()) == 3
+                    if ok:
+                        done = True
+                        break
+                if done:
+                    break
+            assert done, f"harness_{tag}/{case}: nothing passed the screen"
+            lats = np.stack([p[1][0] for p in pairs])
+            codes_stream = [c.copy() for c in log["codes"]]
+            masked = log["masked_segments"]
+            # non-streaming on the same model and source
+            tap.gaps.clear(); log["codes"].clear()
+            m.gpt.get_generator = get_gen
+            lat_calls = []
+
+            def forward2(x, _f=voc_forward):
+                lat_calls.append(int(x.shape[-1]) // 4)
+                return _f(x)
+            m.hifigan.forward = forward2
+            wav_n = RIU.synthesize_utt(m, src, ref, seg_len=1.0)
+            gaps_n = np.concatenate(tap.gaps)
+            p = f"{case}_"
+            out.update({p + "src_seed": src_seed, p + "stop_bias": -1.0 if b is None else float(b), p + "tokens": toks.reshape(-1),
+                        p + "groups": np.array(vo_lens), p + "latents_slice": lats[:, :32], p + "margin": float(gaps[:n_stream].min()),
+                        p + "codes": np.concatenate([c.reshape(-1) for c in codes_stream]),
+                        p + "code_lens": np.array([c.size for c in codes_stream]), p + "masked_segments": masked,
+                        p + "wav_len": wav_s.shape[0], p + "wav_head": wav_s.numpy()[:4096], p + "wav_stride8": wav_s.numpy()[::8],
+                        p + "ns_latent_rows": np.array(lat_calls), p + "ns_wav_len": wav_n.shape[0], p + "ns_margin": float(gaps_n.min()),
+                        p + "ns_wav_head": wav_n.numpy()[:4096], p + "ns_wav_stride8": wav_n.numpy()[::8]})
+            print(f"harness_{tag}/{case}: src seed {src_seed} bias {b}: {n_stream} streamed pairs, groups {vo_lens}, margin "
+                  f"{gaps[:n_stream].min():.2e}, masked segments {masked}, wav {wav_s.shape[0]}; non-streaming rows {lat_calls} wav {wav_n.shape[0]} "
+                  f"margin {gaps_n.min():.2e}")
+        np.savez_compressed(os.path.join(GOLD, f"harness_{tag}.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -471,6 +782,12 @@ def main():
         make_handle_chunks()
     if want("chain"):
         make_chain(GPT, DiscreteVAE)
+    if want("loop"):
+        make_stream_loop(GPT)
+    if want("harness"):
+        make_harness(GPT, DiscreteVAE)
+    if want("harness_tiny"):
+        make_harness(GPT, DiscreteVAE, only=("tiny",))
 
 
 if __name__ == "__main__":

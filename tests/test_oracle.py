@@ -248,3 +248,80 @@ def test_streaming_chain_full_size_vs_reference_classes(gold):
     assert wav.shape[0] == int(g["wav_len"])
     np.testing.assert_allclose(wav[:4096], g["wav_head"], atol=1e-4)
     np.testing.assert_allclose(wav[::16], g["wav_stride16"], atol=1e-4)
+
+
+def test_generation_loop_vs_the_references_own_sample_stream(gold):
+    """tests/golden/stream_loop.npz holds what `NewGenerationMixin.sample_stream` ITSELF (reference layers/stream_generator.py:645-881,
+    imported with four stand-in names and called through the reference's GPT.get_generator, oracle/make_golden.py:make_stream_loop) yields:
+    (a) three rows ending at three different steps -- finished rows yield the pad, the loop ends with the last row, the EOS-step pair is
+    yielded; (b) a run that ends on max_length; (c) GPT.generate (gpt.py:594-608) for the inputs of (b).  O.generate must yield the same."""
+    g = gold("stream_loop")
+    seed = int(g["seed"])
+    dims, w = weights(gcfg.TINY_MODEL_ARGS, seed)
+    w = dict(w)
+    w["mel_head.bias"] = w["mel_head.bias"].clone()
+    w["mel_head.bias"][1025] = float(g["eos_bias"])
+    s = int(g["eos_in_seed"])
+    cond = synth.uniform(s, "cond_latents", (3, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(s, "content_codes", (3, 11), 256)
+    toks, lats, _ = O.generate(w, dims, cond, codes, GREEDY)
+    assert len(set(g["eos_ends"].tolist())) == 3                            # ragged: every row stops at its own step
+    assert toks.shape[1] == g["eos_tokens"].shape[1] == int(g["eos_ends"].max()) + 1
+    assert np.array_equal(toks.numpy(), g["eos_tokens"])
+    for b, e in enumerate(g["eos_ends"]):                                   # latents of live rows (finished rows keep running on pads)
+        np.testing.assert_allclose(lats[b, :e + 1, :32].numpy(), g["eos_latents_slice"][b, :e + 1], atol=1e-4)
+        assert (g["eos_tokens"][b, e:] == 1025).all()
+    w["mel_head.bias"][1025] = 0.0
+    s = int(g["max_in_seed"])
+    cond = synth.uniform(s, "cond_latents", (2, 32, dims["d_model"]), 1.0)
+    codes = synth.integers(s, "content_codes", (2, 13), 256)
+    n = int(g["max_new"])
+    dims_short = dict(dims, max_gen_mel_tokens=n)
+    toks, lats, _ = O.generate(w, dims_short, cond, codes, GREEDY)          # no max_new argument: the cap comes from the model's dims
+    assert toks.shape[1] == n and float(g["max_margins"].min()) > 2e-3
+    assert np.array_equal(toks.numpy(), g["max_tokens"]) and np.array_equal(toks.numpy(), g["generate_tokens"])
+    np.testing.assert_allclose(lats[:, :, :32].numpy(), g["max_latents_slice"], atol=1e-4)
+
+
+def _harness_bundle(tag, g, case):
+    from chain_oracle import synthetic_bundle
+    cfg = gcfg.default_config(tiny=tag == "tiny")
+    W = synthetic_bundle(cfg, int(g["seed"]), int(g["max_new"]))
+    if float(g[case + "_stop_bias"]) >= 0:
+        W["gpt"] = dict(W["gpt"])
+        W["gpt"]["mel_head.bias"] = W["gpt"]["mel_head.bias"].clone()
+        W["gpt"]["mel_head.bias"][1025] = float(g[case + "_stop_bias"])
+    src = synth.synth_audio(int(g[case + "_src_seed"]), "src", 35200)
+    ref = synth.synth_audio(100, "ref", 72000)
+    return W, src, ref
+
+
+def check_harness_result(g, case, st, ns, atol_lat, atol_wav):
+    """st / ns: dict(tokens=[...], latents=[...], wav) of the streaming run and dict(latents, wav) of the non-streaming one"""
+    p = case + "_"
+    assert [int(t.shape[1]) for t in st["tokens"]] == g[p + "groups"].tolist()                  # group boundaries, short tails, EOS pairs
+    assert np.array_equal(torch.cat(st["tokens"], 1).cpu().numpy().reshape(-1), g[p + "tokens"])
+    np.testing.assert_allclose(torch.cat(st["latents"], 1).cpu().numpy()[0, :, :32], g[p + "latents_slice"], atol=atol_lat)
+    wav = st["wav"].cpu().numpy()
+    assert wav.shape[0] == int(g[p + "wav_len"])
+    np.testing.assert_allclose(wav[:4096], g[p + "wav_head"], atol=atol_wav)
+    np.testing.assert_allclose(wav[::8], g[p + "wav_stride8"], atol=atol_wav)
+    assert int(ns["latents"].shape[1]) == int(g[p + "ns_latent_rows"].sum())                  # stop tokens stripped (inference_utils.py:68)
+    wn = ns["wav"].cpu().numpy()
+    assert wn.shape[0] == int(g[p + "ns_wav_len"])
+    np.testing.assert_allclose(wn[:4096], g[p + "ns_wav_head"], atol=atol_wav)
+    np.testing.assert_allclose(wn[::8], g[p + "ns_wav_stride8"], atol=atol_wav)
+
+
+@pytest.mark.parametrize("tag,case", [("tiny", "max"), ("tiny", "eos"), ("full", "max")])
+def test_harness_vs_the_references_own_functions(gold, tag, case):
+    """tests/golden/harness_*.npz: the reference's UNCHANGED synthesize_utt_streaming(seg_len=1.0, stream_chunk_size=8) and synthesize_utt
+    (inference/inference_utils.py:135-217, :23-89) called on a model object made of the reference's own classes with the reference's
+    sample_stream behind get_generator / generate (oracle/make_golden.py:make_harness).  2.2 s source: two 1 s segments and a 0.2 s tail
+    zero-padded to 0.32 s (:43-50).  The oracle's harness restatement must reproduce tokens, group boundaries, latents and both waveforms."""
+    g = gold("harness_" + tag)
+    W, src, ref = _harness_bundle(tag, g, case)
+    assert float(g[case + "_margin"]) > 2e-3 and int(g[case + "_masked_segments"]) == 1
+    st = O.synthesize_utt_streaming(W, src, ref, seg_len=1.0, stream_chunk_size=8)
+    ns = O.synthesize_utt(W, src, ref, seg_len=1.0)
+    check_harness_result(g, case, st, ns, 1e-4, 1e-4)
