@@ -417,7 +417,7 @@ def streams_leg(device, rank, streams=8, weights="bf16_kv", steps=3):
     torch.cuda.synchronize()
     step_us = ev[0].elapsed_time(ev[1]) / (n - GROUP) * 1e3
     variant = wl.eng.decode_variant()
-    wb, kvb = (4, 4) if weights == "fp32" else (2, 2 if weights == "bf16_kv" else 4)
+    wb, kvb = (4, 4) if weights == "fp32" else (2, 2 if weights in ("bf16_kv", "bf16_act") else 4)
     s_mid = wl.P + 1 + n // 2
     by = step_bytes(wl.dims, s_mid, wb, kvb) + (streams - 1) * (2 * wl.dims["n_layer"] * (s_mid + 1) * wl.dims["d_model"]) * kvb
     traffic = None
@@ -606,7 +606,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[3] / configs[4] / prefill legs")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-start probe (first utterance after model_init, with / without warm-up)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU (1 = headline configuration)")
-    ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv"],
+    ap.add_argument("--weights", default="fp32", choices=["fp32", "bf16", "bf16_kv", "bf16_act"],
                     help="GPT weight / KV-cache storage (fp32 = headline configuration; bf16_kv with --streams 8 = BASELINE configs[3])")
     args = ap.parse_args()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -700,7 +700,7 @@ def main():
                                                         torch.zeros(1, wl.Tc, device=device, dtype=torch.int32)), want_outputs=False)
         reps = 40
         wb = 4 if args.weights == "fp32" else 2
-        kvb = 2 if args.weights == "bf16_kv" else 4
+        kvb = 2 if args.weights in ("bf16_kv", "bf16_act") else 4
         fresh()
         whole_us, _ = wl.eng.time_kernel(6, s1, tok, reps)          # launch-per-phase step (the fallback path; the bf16 contexts' path)
         # which step the B = 1 generation loop really replays is the engine's to say (3 = the one-launch step): a device with fewer

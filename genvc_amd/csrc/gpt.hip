@@ -12,6 +12,7 @@
 #include "gpt_kernels.h"
 #include "persist_kernel.h"
 #include "persist_rows.h"
+#include "persist_rows_b16.h"
 #include "sampler.h"
 
 namespace gvc {
@@ -230,6 +231,7 @@ struct gvc_gpt {
     int n_expected = 0;
     float* kv = nullptr;              // [L][2][slots][H][max_seq][hd], fp32 or (kv_bf16) bf16 elements
     int kv_bf16 = 0;
+    int act_bf16 = 0;                 // weight_dtype 3: the one-launch rows step rounds the activations that cross its hand-offs (persist_rows_b16.h)
     size_t kv_layer_stride = 0;       // floats per (layer, k|v)
     float *x = nullptr, *a = nullptr, *q = nullptr, *h = nullptr, *part = nullptr, *work = nullptr;
     long long work_cap = 0;
@@ -344,8 +346,10 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
     if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
     c->bf16 = D.weight_dtype >= 1;
-    c->kv_bf16 = D.weight_dtype == 2;
-    GVC_REQUIRE(D.weight_dtype >= 0 && D.weight_dtype <= 2, GVC_ERR_ARG, "weight_dtype must be 0 (fp32), 1 (bf16 weights) or 2 (bf16 weights + KV cache)");
+    c->kv_bf16 = D.weight_dtype >= 2;
+    c->act_bf16 = D.weight_dtype == 3;
+    GVC_REQUIRE(D.weight_dtype >= 0 && D.weight_dtype <= 3, GVC_ERR_ARG,
+                "weight_dtype must be 0 (fp32), 1 (bf16 weights), 2 (bf16 weights + KV cache) or 3 (2 + bf16 activations on the one-launch rows step)");
     if (c->bf16) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->wh, (L * 12 * d * d + V * d + 64) * sizeof(unsigned short)));
         unsigned short* hq = c->wh;
@@ -862,7 +866,8 @@ typedef void (*rows_fn)(const RowsArgs);
 template <int HDR>
 static const void* rows_kernel_hd(const gvc_gpt* c, int R) {
     rows_fn f;
-    if (c->kv_bf16) f = R == 8 ? (rows_fn)k_rows_persist<8, 1, 1, HDR> : (rows_fn)k_rows_persist<16, 1, 1, HDR>;
+    if (c->act_bf16) f = R == 8 ? (rows_fn)k_rows_persist_b16<8, HDR> : (rows_fn)k_rows_persist_b16<16, HDR>;
+    else if (c->kv_bf16) f = R == 8 ? (rows_fn)k_rows_persist<8, 1, 1, HDR> : (rows_fn)k_rows_persist<16, 1, 1, HDR>;
     else if (c->bf16) f = R == 8 ? (rows_fn)k_rows_persist<8, 1, 0, HDR> : (rows_fn)k_rows_persist<16, 1, 0, HDR>;
     else f = R == 8 ? (rows_fn)k_rows_persist<8, 0, 0, HDR> : (rows_fn)k_rows_persist<16, 0, 0, HDR>;
     return (const void*)f;
@@ -884,6 +889,18 @@ static void rows_pack_layer(gvc_gpt* c, int l) {
     const GptLayer& ly = c->layers[l];
     const int wsh = c->bf16 ? 1 : 0;
     float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(c->r_wpack) + (size_t)l * kPG * (kRWgLayerBytes >> wsh));
+    if (c->act_bf16) {
+        // bf16-activation mode: octet-major bf16 groups with the LayerNorm gains folded into c_attn / c_fc, and the constants that go with them
+        const int d = kRD;
+        float* f = c->r_lnfold + (size_t)l * 14 * d;
+        hipLaunchKernelGGL(k_pack_rows_weights_b16, dim3(2048), dim3(256), 0, 0, reinterpret_cast<pu32x4*>(dst), (const float*)ly.qkv_w,
+                           (const float*)ly.proj_w, (const float*)ly.fc_w, (const float*)ly.p2_w, (const float*)ly.ln1_w, (const float*)ly.ln2_w);
+        hipLaunchKernelGGL(k_rows_ln_fold_b16, dim3(3 * d / 4), dim3(256), 0, 0, f, f + 3 * d, (const float*)ly.qkv_w, (const float*)ly.ln1_w,
+                           (const float*)ly.ln1_b, (const float*)ly.qkv_b, 3 * d, d);
+        hipLaunchKernelGGL(k_rows_ln_fold_b16, dim3(4 * d / 4), dim3(256), 0, 0, f + 6 * d, f + 10 * d, (const float*)ly.fc_w, (const float*)ly.ln2_w,
+                           (const float*)ly.ln2_b, (const float*)ly.fc_b, 4 * d, d);
+        return;
+    }
     if (wsh) hipLaunchKernelGGL(k_pack_rows_weights<1>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
                                 (const float*)ly.fc_w, (const float*)ly.p2_w);
     else hipLaunchKernelGGL(k_pack_rows_weights<0>, dim3(2048), dim3(256), 0, 0, dst, (const float*)ly.qkv_w, (const float*)ly.proj_w,
@@ -926,7 +943,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern[1], kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern[0], kPThreads, c->r_lds) != hipSuccess || per_cu < 1 ||
         hipMalloc((void**)&c->r_wpack, (size_t)L * kPG * (kRWgLayerBytes >> wsh)) != hipSuccess ||
-        hipMalloc((void**)&c->r_bufs, rows_buf_bytes()) != hipSuccess ||
+        hipMalloc((void**)&c->r_bufs, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes()) != hipSuccess ||
         hipMalloc((void**)&c->r_lnfold, (size_t)L * 14 * kRD * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->r_layers, L * sizeof(RowsLayer)) != hipSuccess) {
         rows_persist_release(c);
@@ -942,7 +959,7 @@ static int rows_persist_prepare(gvc_gpt* c) {
         rows_pack_layer(c, l);
     }
     if (hipGetLastError() != hipSuccess || hipMemcpy(c->r_layers, t.data(), L * sizeof(RowsLayer), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(c->r_bufs, 0xff, rows_buf_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        hipMemset(c->r_bufs, 0xff, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes()) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         rows_persist_release(c);
         return GVC_OK;
     }
@@ -973,6 +990,8 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     A.loader_depth = rows_loader_depth;
     static const int rows_opt = getenv("GVC_ROWS_OPT") ? atoi(getenv("GVC_ROWS_OPT")) : 1;
     A.opt = rows_opt;
+    static const int rows_copies = getenv("GVC_ROWS_COPIES") ? atoi(getenv("GVC_ROWS_COPIES")) : 8;
+    A.copies = rows_copies == 1 ? 1 : 8;
     // keys of a (row, head) over 2 / 4 workgroups: 8 rows from 80 / 160 cached positions (one 80-key pass per workgroup; 744 vs 766 us
     // per step at 48-112 keys, 815 vs 827 at 110-250), 16 rows from 128 / 288 (their chunk merge gathers 64 KB per chunk: 1068 vs 1104 us)
     A.split1 = c->r_split1 > 0 ? c->r_split1 : (rows <= 8 ? 80 : 128);
@@ -1095,7 +1114,7 @@ static int check_ready(gvc_gpt* c) {
         c->persist = 0;
         for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
         c->graphs.clear();
-        if (c->r_bufs) (void)hipMemset(c->r_bufs, 0xff, rows_buf_bytes());
+        if (c->r_bufs) (void)hipMemset(c->r_bufs, 0xff, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes());
         if (c->p_epoch) (void)hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned));
         *c->seam_err_host = 0;
         c->fallbacks += 1;
@@ -1489,7 +1508,7 @@ extern "C" int gvc_gpt_rearm(gvc_gpt* c) {
     GVC_CHECK_HIP(hipDeviceSynchronize());
     for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
     c->graphs.clear();
-    if (c->r_bufs) GVC_CHECK_HIP(hipMemset(c->r_bufs, 0xff, rows_buf_bytes()));
+    if (c->r_bufs) GVC_CHECK_HIP(hipMemset(c->r_bufs, 0xff, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes()));
     if (c->p_epoch) GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned)));
     GVC_CHECK_HIP(hipDeviceSynchronize());
     c->persist = c->persist_cfg;

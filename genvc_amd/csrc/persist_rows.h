@@ -79,6 +79,7 @@ struct RowsArgs {
     int split1, split2;             // cached positions from which the keys of a (row, head) take 2 / 4 workgroups
     int poll_all;                   // gathers of up to this many 16-byte pieces per lane re-request everything in every poll pass
     int loader_depth;               // LDS-DMA fills in flight per loader wave (1 or 2)
+    int copies;                     // bf16-activation mode (persist_rows_b16.h): per-XCD copies of the gathered hand-off buffers (1 or 8)
     int opt;                        // A/B switches (GVC_ROWS_OPT, default 1): bit 0: every wave of phase B gathers q itself (else wave 0 -> LDS -> barrier)
     unsigned long long* dbg;
 };

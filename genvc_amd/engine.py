@@ -34,7 +34,7 @@ class GptEngine:
         max_seq = max_seq or ((dims["max_seq"] + 63) // 64) * 64
         cd = _lib.GptDims(dims["n_layer"], dims["d_model"], dims["n_head"], dims["num_audio_tokens"],
                           dims["max_mel_pos"], dims["max_text_pos"], dims["number_text_tokens"], max_seq,
-                          max_slots, max_rows, {"fp32": 0, "bf16": 1, "bf16_kv": 2}[weight_dtype])
+                          max_slots, max_rows, {"fp32": 0, "bf16": 1, "bf16_kv": 2, "bf16_act": 3}[weight_dtype])
         self._h = C.c_void_p()
         check(lib().gvc_gpt_create(C.byref(cd), C.byref(self._h)), "gvc_gpt_create")
 

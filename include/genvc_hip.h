@@ -64,7 +64,13 @@ typedef struct gvc_gpt_dims {
                              rounded to bf16 at bind time; the decode step and the skinny MFMA path stream bf16 copies (half the HBM bytes),
                              every product and accumulation stays fp32; KV cache and activations stay fp32.
                              2: as 1, and the KV cache holds bf16 too (k / v rounded to nearest even where they enter the cache,
-                             widened to fp32 where the attention kernels use them; half the cache bytes) */
+                             widened to fp32 where the attention kernels use them; half the cache bytes).
+                             3: as 2, and the one-launch rows step (2..16 rows that continue cached sequences: batched decode steps, cached
+                             chunk prefills; csrc/persist_rows_b16.h) rounds the four activations that cross its hand-offs -- x into LN1, the
+                             attention output, x' into LN2, the gelu output -- to bf16 where they are published and multiplies on bf16 MFMAs with
+                             fp32 accumulation (LayerNorm gain folded into the packed bf16 weights); residual stream, softmax, statistics and q stay
+                             fp32.  The other paths of such a context (one stream, full prefills, 17+ streams) compute as mode 2.  Not bit-exact
+                             against any reference by construction: oracle rounding points `dims["act_bf16"]` */
 } gvc_gpt_dims;
 
 int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out);

@@ -240,20 +240,46 @@ def compute_embeddings(w, dims, cond_latents, codes):
     return emb, fake
 
 
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _ln_fold_bf16(x, w, ln, proj):
+    """The build's bf16-activation mode (include/genvc_hip.h: weight_dtype 3; csrc/persist_rows_b16.h) of `LN -> Conv1D`: the residual
+    stream stays fp32, the row that crosses the hand-off is x~ = bf16(x), the LayerNorm gain is folded into the bf16 weights at pack time
+    (W' = bf16(W g), W the bf16-rounded weight the context holds) and the LayerNorm bias into a per-output constant (C = b_ln W + b):
+    y = ((x~ - mean(x~)) rstd(x~)) W' + C, fp32 accumulation.  What a bf16-autocast run of the reference would round is LN(x) instead of x
+    -- the same 2^-9 relative step one normalisation earlier."""
+    xt = _bf16(x)
+    mean = xt.mean(-1, keepdim=True)
+    var = (xt - mean).pow(2).mean(-1, keepdim=True)
+    a = (xt - mean) * torch.rsqrt(var + 1e-5)
+    W = w[proj + ".weight"]
+    Wf = _bf16(W * w[ln + ".weight"][:, None])
+    return a @ Wf + (w[ln + ".bias"] @ W + w[proj + ".bias"])
+
+
 def gpt_blocks(w, dims, x, cache=None):
     """HF GPT2Model block stack on rows x [B,T,d]; `cache` = list of (K,V) [B,H,S,hd] or None.
 
     Conv1D: y = x @ W[in,out] + b.  Causal within the new rows, full view of the cache.
     Returns (ln_f(h), new_cache).
+    dims["act_bf16"] (build-only mode, see _ln_fold_bf16): the four activations that cross a hand-off of the one-launch rows step --
+    x into LN1, the attention output, x' into LN2, the gelu output -- are rounded to bf16 where they are published; weights (mode 1) and
+    k / v (mode 2) are rounded as before; residual sums, softmax, LayerNorm statistics and every accumulation stay fp32.
     """
+    act = bool(dims.get("act_bf16"))
     B, T, d = x.shape
     H = dims["n_head"]
     hd = d // H
     new_cache = []
     for l in range(dims["n_layer"]):
         p = f"gpt.h.{l}."
-        a = _ln(x, w, p + "ln_1")
-        qkv = a @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
+        if act:
+            qkv = _ln_fold_bf16(x, w, p + "ln_1", p + "attn.c_attn")
+        else:
+            a = _ln(x, w, p + "ln_1")
+            qkv = a @ w[p + "attn.c_attn.weight"] + w[p + "attn.c_attn.bias"]
         q, k, v = qkv.split(d, dim=-1)
         sh = lambda t: t.reshape(B, T, H, hd).transpose(1, 2)
         q, k, v = sh(q), sh(k), sh(v)
@@ -273,9 +299,14 @@ def gpt_blocks(w, dims, x, cache=None):
             s = s.masked_fill(j > i, torch.finfo(s.dtype).min)
         pr = torch.softmax(s, dim=-1)
         o = torch.matmul(pr, v).transpose(1, 2).reshape(B, T, d)
+        if act:
+            o = _bf16(o)
         x = x + (o @ w[p + "attn.c_proj.weight"] + w[p + "attn.c_proj.bias"])
-        m = _ln(x, w, p + "ln_2")
-        h = gelu_new(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
+        if act:
+            h = _bf16(gelu_new(_ln_fold_bf16(x, w, p + "ln_2", p + "mlp.c_fc")))
+        else:
+            m = _ln(x, w, p + "ln_2")
+            h = gelu_new(m @ w[p + "mlp.c_fc.weight"] + w[p + "mlp.c_fc.bias"])
         x = x + (h @ w[p + "mlp.c_proj.weight"] + w[p + "mlp.c_proj.bias"])
     return _ln(x, w, "gpt.ln_f"), new_cache
 
@@ -292,7 +323,9 @@ def gpt_prefill(w, dims, prefix_emb):
     B = prefix_emb.shape[0]
     row = w["mel_embedding.weight"][dims["start_audio_token"]] + w["mel_pos_embedding.emb.weight"][0]
     emb = torch.cat([prefix_emb, row.view(1, 1, -1).expand(B, 1, -1)], dim=1)
-    h, cache = gpt_blocks(w, dims, emb)
+    # a weight_dtype-3 context rounds activations on the one-launch rows step only (decode steps, cached chunk prefills); a full
+    # prefill runs on the GEMM path with fp32 activations: dims["act_bf16"] does not apply here unless the caller says so
+    h, cache = gpt_blocks(w, dict(dims, act_bf16=bool(dims.get("act_bf16_prefill"))), emb)
     z, logits = head(w, h[:, -1])
     return z, logits, cache
 

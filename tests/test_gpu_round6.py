@@ -117,3 +117,66 @@ def test_config3_bf16_weights_and_cache_at_full_depth_vs_oracle(B, variant):
     assert torch.equal(toks.long(), ref_t), "ids differ from the oracle on a margin-screened input"
     np.testing.assert_allclose(lats.numpy(), ref_l.numpy(), atol=2e-3)
     eng.close()
+
+
+def _act_bf16_case(L, B, Tc, n, H=4, in_seed=100):
+    """HIP weight_dtype 3 run + the oracle's act_bf16 run + the oracle re-run on an input perturbed by 2e-7 relative (its own
+    reproducibility: rounding activations to bf16 makes the map discontinuous, a deviation of 1e-5 becomes 1e-3 within a layer)"""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    from test_gpu_gpt import run_generate, _round_bf16
+    torch.cuda.empty_cache()
+    dims = gcfg.gpt_dims(dict(gcfg.DEFAULT_MODEL_ARGS, gpt_layers=L, gpt_n_heads=H))
+    w = synth.make_weights(5, synth.gpt_weight_spec(dims), device=DEV)
+    eng = GptEngine(dims, max_slots=max(B, 8), max_rows=4096, weight_dtype="bf16_act")
+    eng.bind(w)
+    wr = _round_bf16({k: v.cpu() for k, v in w.items()})
+    dims_o = dict(dims, kv_bf16=True, act_bf16=True)
+    cond = synth.uniform(in_seed, "cond_latents", (B, 32, 1024), 1.0)
+    codes = synth.integers(in_seed, "content_codes", (B, Tc), 256)
+    _, toks, lats = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() == 5, "the decode steps did not run on the one-launch rows step"
+    torch.cuda.synchronize()
+    eng.health()
+    eng.close()
+    ref_t, ref_l, ref_logits = O.generate(wr, dims_o, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    g = torch.Generator().manual_seed(0)
+    cond2 = cond * (1 + 2e-7 * torch.randn(cond.shape, generator=g))
+    # (teacher-forced on the first run's tokens: the yardstick is the latents' reproducibility, not the loop's)
+    _, cache = None, None
+    prefix, ids = O.compute_embeddings(wr, dims_o, cond2, codes)
+    z, _, cache = O.gpt_prefill(wr, dims_o, prefix)
+    pert = [z]
+    for j in range(1, n):
+        z, _, cache = O.gpt_decode_step(wr, dims_o, cache, ref_t[:, j - 1], j)
+        pert.append(z)
+    pert_l = torch.stack(pert, 1)
+    margins = _greedy_margins(O, ref_t, ref_logits, B, Tc, n)
+    return toks.long(), lats, ref_t, ref_l, pert_l, margins
+
+
+@pytest.mark.parametrize("L,B,Tc,n,H", [(2, 8, 13, 24, 4), (30, 8, 13, 24, 4), (2, 5, 120, 16, 4), (2, 12, 13, 12, 4), (2, 8, 13, 16, 16), (2, 3, 300, 10, 8)],
+                         ids=["8_streams", "8_streams_full_depth", "key_chunks", "16_rows", "16_heads", "8_heads_4_chunks"])
+def test_rows_step_bf16_activations_vs_oracle(L, B, Tc, n, H):
+    """weight_dtype 3 (csrc/persist_rows_b16.h): the one-launch rows step with bf16 activations across its hand-offs and bf16 MFMAs, against
+    the oracle with the same rounding points (`dims["act_bf16"]`; reference block math gpt_inference.py:92-112, loop stream_generator.py:809-881).
+    bf16 cannot be bit-exact; the claim, per SURVEY: agreement rate + tolerance --
+      * step 0 (the prefill's row: GEMM path, fp32 activations) agrees to 2e-3 like mode 2;
+      * the latents of the rows steps deviate from the oracle by no more than the ORACLE ITSELF deviates when its input moves by 2e-7
+        relative (median and 99.9 % quantile within 2x of that yardstick): the kernel is inside the oracle's reproducibility ball;
+      * >= 85 % of the greedy ids equal the oracle's, and a first divergence only where the oracle's own top-1 / top-2 gap is < 1e-2."""
+    toks, lats, ref_t, ref_l, pert_l, margins = _act_bf16_case(L, B, Tc, n, H)
+    np.testing.assert_allclose(lats[:, 0].numpy(), ref_l[:, 0].numpy(), atol=2e-3)
+    agree = toks == ref_t
+    first = min(int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else n for b in range(B))
+    assert first >= 2
+    d_hip = (lats[:, 1:first] - ref_l[:, 1:first]).abs().flatten()
+    d_ref = (pert_l[:, 1:first] - ref_l[:, 1:first]).abs().flatten()
+    q = lambda t, p: float(torch.quantile(t[::max(1, t.numel() // 200000)].double(), p))
+    assert q(d_hip, 0.5) <= 2.0 * q(d_ref, 0.5) + 1e-4, (q(d_hip, 0.5), q(d_ref, 0.5))
+    assert q(d_hip, 0.999) <= 2.0 * q(d_ref, 0.999) + 1e-3, (q(d_hip, 0.999), q(d_ref, 0.999))
+    assert float(agree.float().mean()) >= 0.85, float(agree.float().mean())
+    for b in range(B):
+        bad = (~agree[b]).nonzero()
+        if len(bad):
+            assert float(margins[b, int(bad[0])]) < 1e-2, (b, int(bad[0]), float(margins[b, int(bad[0])]))
