@@ -168,6 +168,16 @@ class Workload:
         return self.toks
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(wl, budget_s=10.0, gpu=None):
     """The oracle (port) on the host cores, one 1 s chunk at a time (ContentVec, DVAE+VQ, prefix, prefill, 24 steps).
     gpu = (token ids [n_chunks * 24], [content codes per chunk]) of the SAME utterance (src[0], ref[0], greedy) from the timed HIP
@@ -186,13 +196,15 @@ def cpu_baseline(wl, budget_s=10.0, gpu=None):
     cond0 = torch.zeros(1, 32, dims["d_model"])
     codes0 = torch.zeros(1, 13, dtype=torch.long)
     best = None
-    for nt in (8, 16, 32, 64, os.cpu_count() or 8):
+    sweep = []
+    for nt in sorted({8, 16, 32, 64, os.cpu_count() or 8}):
         if nt > (os.cpu_count() or 8):
             continue
         torch.set_num_threads(nt)
         t0 = time.time()
         O.generate(w, dims, cond0, codes0, greedy, max_new=3, stop_on_eos=False)
         t = time.time() - t0
+        sweep.append({"threads": nt, "seconds_prefill48_plus_2_steps": round(t, 3)})
         if best is None or t < best[0]:
             best = (t, nt)
     cores = best[1]
@@ -201,6 +213,25 @@ def cpu_baseline(wl, budget_s=10.0, gpu=None):
     cond = O.get_gpt_cond_latents(w, wl.ref[0].cpu(), norms)
     t_ref = time.time() - t0
     src = wl.src[0][:, 0].cpu()
+    # prefill alone (48 rows) and the CPU path's first-chunk latency: mel + Perceiver, ContentVec, DVAE + VQ, prefill, 8 decode
+    # steps, x4 interpolation + HiFi-GAN on the 8 latents -- the reference's clock window (inference_utils.py:148, 208-211) on the host cores
+    wv = {k[len("hifigan."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("hifigan.")}
+    t0 = time.time()
+    feat0 = O.hubert_extract_features(wh, hcfg, src[0:1])
+    codes_0 = O.dvae_get_codebook_indices(wd, feat0.transpose(1, 2))
+    t_front = time.time() - t0
+    prefix0, _ = O.compute_embeddings(w, dims, cond, codes_0)
+    O.gpt_prefill(w, dims, prefix0)
+    t0 = time.time()
+    O.gpt_prefill(w, dims, prefix0)
+    t_prefill = time.time() - t0
+    t0 = time.time()
+    _, lat8, _ = O.generate(w, dims, cond, codes_0, greedy, max_new=GROUP, stop_on_eos=False)
+    t_gen8 = time.time() - t0
+    t0 = time.time()
+    O.vocode_latents(wv, m.hifigan.cfg, lat8)
+    t_voc = time.time() - t0
+    first_chunk_ms = (t_ref + t_front + t_gen8 + t_voc) * 1e3
 
     kept = {}
 
@@ -253,7 +284,11 @@ def cpu_baseline(wl, budget_s=10.0, gpu=None):
             "ms_per_chunk": t_chunk * 1e3, "ms_per_chunk_min_max": [min(times) * 1e3, max(times) * 1e3],
             "note": "host load moves this figure by +-20 % from run to run (0.05-0.07 utterances/s observed); context, not a target",
             "ms_per_decode_token_est": t_chunk * 1e3 / (STEPS_PER_CHUNK + 2),
-            "rtf": utt_s / SRC_SECONDS, "host_cpus": os.cpu_count(), "cpu": platform.processor() or platform.machine()}
+            "rtf": utt_s / SRC_SECONDS, "host_cpus": os.cpu_count(), "cpu": _cpu_model(),
+            "prefill_48_rows_ms": t_prefill * 1e3, "first_chunk_ms": first_chunk_ms,
+            "first_chunk_stages_ms": {"mel + Perceiver": t_ref * 1e3, "ContentVec + DVAE/VQ": t_front * 1e3,
+                                      "prefill + 8 decode steps": t_gen8 * 1e3, "x4 interpolation + HiFi-GAN (8 tokens)": t_voc * 1e3},
+            "threads_sweep": sweep, "cores_note": f"`cores` = the fastest of the swept thread counts ({cores}); batch-1 GEMVs collapse beyond a few dozen threads"}
 
 
 def offline_leg(wl, rank, world, dist, device):
@@ -386,9 +421,69 @@ def prefill_leg(wl, B=5, Tc=75, reps=6):
     return out
 
 
-def streams_leg(device, rank, streams=8, weights="bf16_kv", steps=3):
-    """BASELINE configs[3]: `streams` concurrent streams on one GPU, bf16 weights + bf16 KV cache (fp32 accumulation), every stream
-    converted as synthesize_utt_streaming converts it alone; the streams share the launches (one decode step for all)."""
+def _round_bf16_weights(w):
+    """the matrices a bf16-weights context rounds at bind time (include/genvc_hip.h: weight_dtype >= 1)"""
+    out = dict(w)
+    for k, v in w.items():
+        if k.endswith(("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")) or k == "mel_head.weight":
+            out[k] = v.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+def streams_parity(wl, weights):
+    """chunk 0 of the leg's utterance 0, all streams: the ids / latents the timed path produced against the CPU oracle with the same storage
+    and rounding points (bf16-rounded weights, k / v rounded into the cache, and for bf16_act the four hand-off activations of the rows step),
+    fed the HIP path's own conditioning latents and content codes.  bf16 modes: an agreement rate and a tolerance, not bit-exactness."""
+    from oracle import genvc_oracle as O
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    m, S, n = wl.model, wl.S, STEPS_PER_CHUNK
+    wl.keep_codes = []
+    wl.utterance(0)
+    torch.cuda.synchronize()
+    codes = wl.keep_codes[0].long().cpu()
+    wl.keep_codes = None
+    toks, lats = wl.toks[:, :n].long().cpu(), wl.lats[:, :n].cpu()
+    cond = m.get_gpt_cond_latents(wl.ref[0], 24000).cpu().expand(S, -1, -1).contiguous()
+    w = {k[len("gpt."):]: v.detach().cpu() for k, v in m.state_dict().items() if k.startswith("gpt.")}
+    dims = dict(wl.dims)
+    if weights != "fp32":
+        w = _round_bf16_weights(w)
+        dims.update(kv_bf16=weights in ("bf16_kv", "bf16_act"), act_bf16=weights == "bf16_act")
+    greedy = dict(gcfg.DEFAULT_SAMPLING, top_k=1)
+    t0 = time.time()
+    ref_t, ref_l, ref_logits = O.generate(w, dims, cond, codes, greedy, max_new=n, stop_on_eos=False)
+    _, ids0 = O.compute_embeddings(w, dims, cond, codes)
+    margins = []
+    for i in range(n):
+        sc = O.process_logits(ref_logits[i], torch.cat([ids0, ref_t[:, :i]], 1), greedy["repetition_penalty"], 1.0, 0, 1.0)
+        t2 = sc.topk(2, -1)[0]
+        margins.append(t2[:, 0] - t2[:, 1])
+    margins = torch.stack(margins, 1)
+    agree = toks == ref_t
+    first = None
+    common = n
+    for b in range(S):
+        bad = (~agree[b]).nonzero()
+        if len(bad):
+            j = int(bad[0])
+            common = min(common, j)
+            if first is None or j < first["step"]:
+                first = {"stream": b, "step": j, "oracle_margin": float(margins[b, j])}
+    d = (lats[:, :max(common, 1)] - ref_l[:, :max(common, 1)]).abs()
+    return {"streams": S, "tokens_compared": S * n, "agreement": float(agree.float().mean()), "first_divergence": first,
+            "oracle_min_margin": float(margins.min()), "latents_abs_dev_median": float(d.median()), "latents_abs_dev_max": float(d.max()),
+            "latents_mean_abs": float(ref_l.abs().mean()), "oracle_seconds": time.time() - t0,
+            "what": "chunk 0 of utterance 0, every stream: ids and latents of the timed HIP path vs the CPU oracle with the same rounding points "
+                    "(oracle/genvc_oracle.py: kv_bf16" + (", act_bf16" if weights == "bf16_act" else "") + "); unscreened input.  bf16 activations "
+                    "make the map discontinuous: two correct implementations sit ~2e-3 (median) apart after one layer "
+                    "(tests/test_gpu_round6.py measures the oracle against itself under a 2e-7 input perturbation), so the claim is the "
+                    "agreement rate and a first divergence only at a small oracle margin"}
+
+
+def streams_leg(device, rank, streams=8, weights="bf16_act", steps=3, parity=True):
+    """BASELINE configs[3]: `streams` concurrent streams on one GPU, bf16 weights + bf16 KV cache (+ bf16 activations across the hand-offs of
+    the one-launch rows step with weights = "bf16_act": csrc/persist_rows_b16.h; fp32 accumulation everywhere), every stream converted as
+    synthesize_utt_streaming converts it alone; the streams share the launches (one decode step for all)."""
     wl = Workload(device, rank, streams, weights, max_slots=max(8, streams))
     wl.utterance(0)
     torch.cuda.synchronize()
@@ -420,17 +515,26 @@ def streams_leg(device, rank, streams=8, weights="bf16_kv", steps=3):
     wb, kvb = (4, 4) if weights == "fp32" else (2, 2 if weights in ("bf16_kv", "bf16_act") else 4)
     s_mid = wl.P + 1 + n // 2
     by = step_bytes(wl.dims, s_mid, wb, kvb) + (streams - 1) * (2 * wl.dims["n_layer"] * (s_mid + 1) * wl.dims["d_model"]) * kvb
-    traffic = None
+    kname = {"bf16_act": "k_rows_persist_b16<8>", "bf16_kv": "k_rows_persist<8,1,1>", "bf16": "k_rows_persist<8,1,0>", "fp32": "k_rows_persist<8>"}[weights]
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and weights == "bf16_kv" and streams == 8:     # (the PMC passes of that instantiation: scripts/profile_round.sh)
-        traffic = json.load(open(pmc)).get("k_rows_persist<8,1,1>")
+    if os.path.exists(pmc) and streams == 8:
+        tj = json.load(open(pmc))
+        if kname in tj:
+            traffic = tj[kname]
+            traffic_source = ("imported from profiles/pmc_traffic.json (a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this kernel, "
+                              + tj.get("_source_" + kname, "see the file's notes") + "); `achieved` / `frac` are this run's timing")
     out = {"workload": f"GenVC_large (:= GenVC_small dims) streaming, 1 s chunks, top_k=1, {streams} concurrent streams on one GPU stepped "
                        f"together, weights/KV {weights}, fp32 accumulation (BASELINE configs[3])",
+           "weights": weights,
            "utts_per_s": streams / dt, "rtf_per_stream": dt / SRC_SECONDS, "first_chunk_latency_ms": first_ms,
            "decode_step_us": step_us, "decode_variant": variant,
            "roofline": {"bound": "hbm", "achieved": by / (step_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": by,
-                        "kernel": "k_rows_persist<8> (one decode step of 8 streams, sampler + head launches included in the time)"}}
+                        "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                        "bytes_per_launch": by,
+                        "kernel": f"{kname} (one decode step of {streams} streams, sampler + head launches included in the time)"}}
+    if parity:
+        out["parity"] = streams_parity(wl, weights)
     del wl
     torch.cuda.empty_cache()
     return out
@@ -459,6 +563,7 @@ class Config4:
         self.slots = torch.arange(self.B, device=dev, dtype=torch.int32)
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         self.dev = dev
+        self.repass = False
 
     def utterance(self, record=False):
         wl, m, eng, B, n = self.wl, self.wl.model, self.wl.eng, self.B, self.n_new
@@ -494,7 +599,9 @@ class Config4:
             eng.generate(self.slots, ids, ids_len, fin, self.sp, g, k, toks, lats, max_keys=P + 1 + g + k)
         if record:
             ev[4].record()
-        lat = eng.latents(self.slots, prefix, toks)                       # latent re-pass (gpt.py:375-508), 5 x (110 + 141 + 4) rows
+        # the latents the vocoder takes: the decode loop's own (no stop token is ever emitted here: the re-pass would recompute exactly
+        # these 141 rows per segment, gpt.py:375-508, 5 x (110 + 141 + 4) rows -- `repass` runs it, as the reference does)
+        lat = eng.latents(self.slots, prefix, toks) if self.repass else lats
         if record:
             ev[5].record()
         self.wav = m.hifigan.forward_latents(lat.reshape(1, B * n, -1), 4)    # one vocoder call over all latents (inference_utils.py:79-87)
@@ -525,6 +632,12 @@ def config4_leg(wl, rank, world, dist, device, steps=3):
     c4.utterance(record=True)
     torch.cuda.synchronize()
     st = [c4.ev[i].elapsed_time(c4.ev[i + 1]) for i in range(6)]
+    # the reference's second forward pass (inference_utils.py:71-76), which the default path no longer runs: its cost and what it changes
+    c4.repass = True
+    c4.utterance(record=True)
+    torch.cuda.synchronize()
+    repass_ms = c4.ev[4].elapsed_time(c4.ev[5])
+    c4.repass = False
     T = c4.P + 1
     fl_prefill = prefill_flops(wl.dims, c4.B, T)
     d = wl.dims["d_model"]
@@ -534,10 +647,12 @@ def config4_leg(wl, rank, world, dist, device, steps=3):
     fl_perc = perc(563) + perc(376)
     return {"workload": f"GenVC_large (:= GenVC_small dims) non-streaming, {C4_SRC_SECONDS:.0f} s source + {C4_REF_SECONDS:.0f} s reference, "
                         f"top_k={C4_TOP_K} (BASELINE configs[4]): Perceiver on 563 + 376 mel frames; five 6 s segments as one batch "
-                        f"(5 x {T}-row prefill, 5-stream sampled decode x {c4.n_new} steps, latent re-pass, one vocoder call); one utterance per GPU at a time",
+                        f"(5 x {T}-row prefill, 5-stream sampled decode x {c4.n_new} steps, one vocoder call over the decode loop's latents -- the reference's latent "
+                        f"re-pass recomputes the same vectors, SURVEY.md 8a row 12, and is kept behind repass_latents=True); one utterance per GPU at a time",
             "n_gpus": world, "utts_per_s": steps * world / dt, "rtf": dt / steps / C4_SRC_SECONDS, "ms_per_utterance": dt / steps * 1e3,
             "stages_ms": {"mel+perceiver(563+376 frames)": st[0], "contentvec+dvae(5 x 6 s)": st[1], f"prefix+prefill(5x{T})": st[2],
-                          f"decode({c4.n_new} steps x 5 streams, top_k={C4_TOP_K})": st[3], "latent re-pass": st[4], "vocoder": st[5]},
+                          f"decode({c4.n_new} steps x 5 streams, top_k={C4_TOP_K})": st[3], "vocoder": st[5]},
+            "latent_repass_ms_when_enabled": repass_ms,
             "prefill_mfma_frac": fl_prefill / (st[2] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "perceiver_mfma_frac_incl_mel": fl_perc / (st[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "decode_step_us": st[3] / c4.n_new * 1e3, "decode_variant": wl.eng.decode_variant()}
@@ -683,6 +798,16 @@ def main():
         ones = [torch.zeros(1, device=device, dtype=torch.int32) for _ in range(world)]
         dist.all_gather(ones, torch.ones(1, device=device, dtype=torch.int32))
         rccl_ranks = int(torch.cat(ones).sum().item())
+        assert rccl_ranks == world == args.gpus, f"{rccl_ranks} ranks answered the collective, --gpus {args.gpus}"
+    # which physical device every rank ran on (an N > 1 line must show N distinct GPUs unless the dry-run hook put them on one)
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    my_uuid = str(getattr(props, "uuid", "")) or f"{props.name}#{local}"
+    device_uuids = [my_uuid]
+    if dist is not None:
+        device_uuids = [None] * world
+        dist.all_gather_object(device_uuids, my_uuid)
+        if not os.environ.get("GVC_BENCH_SAME_DEVICE"):
+            assert len(set(device_uuids)) == world, f"{world} ranks on {len(set(device_uuids))} distinct devices: {device_uuids}"
 
     if rank == 0:
         # latency / per-stage numbers from one recorded utterance (device events on the launch stream)
@@ -742,16 +867,21 @@ def main():
             cand = [i for i, k in enumerate(kern) if "gemv" in k["kernel"] and "head" not in k["kernel"]]
             dom = max(cand, key=lambda i: kern[i]["avg_us"] * kern[i]["launches_per_step"])
         achieved = kern[dom]["bytes"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and args.weights == "fp32":      # the PMC passes were taken on the fp32 build
-            traffic = json.load(open(pmc)).get(kern[dom]["kernel"].split(" ")[0])
+            tj = json.load(open(pmc))
+            key = kern[dom]["kernel"].split(" ")[0]
+            if key in tj:
+                traffic = tj[key]
+                traffic_source = ("imported from profiles/pmc_traffic.json (a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run of this kernel, "
+                                  + tj.get("_source_" + key, "see the file's notes") + "); `achieved` / `frac` are this run's timing")
         n_utts = args.steps * world * args.streams
         ms_step = dt / args.steps * 1e3
         out = {
             "metric": "utterances/s (streaming, 1 s chunks; with RTF and first-chunk latency)",
             "value": n_utts / dt, "unit": "utterances/s", "n_gpus": world,
-            "collective_backend": None if dist is None else dist.get_backend(), "rccl_ranks": rccl_ranks,
+            "collective_backend": None if dist is None else dist.get_backend(), "rccl_ranks": rccl_ranks, "device_uuids": device_uuids,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.weights == "fp32" else "bf16 storage, f32 arithmetic", "data": "synthetic", "weights": args.weights,
@@ -768,7 +898,7 @@ def main():
                        "excluded_from_timed_path": [],
                        "parallelism": f"replicas x{world}, utterances sharded by rank, all_gather of token ids"},
             "roofline": {"bound": "hbm", "kernel": kern[dom]["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": kern[dom]["bytes"], "avg_us": kern[dom]["avg_us"],
                          "decode_step_us": kern[dom]["avg_us"] if one_launch else whole_us,
                          "decode_step_us_launch_per_phase": whole_us},
@@ -798,7 +928,13 @@ def main():
             out["parity_in_bench"] = cb.pop("parity")
             out["cpu_baseline"] = cb
         if do_extra and world == 1:
-            out["streams8_bf16_kv"] = streams_leg(device, rank)
+            # BASELINE configs[3]: bf16 weights + KV cache + bf16 activations across the rows step's hand-offs (weight_dtype 3), with its parity
+            # block; beside it the same leg with fp32 activations (weight_dtype 2: what this key measured up to round 5)
+            leg = streams_leg(device, rank, weights="bf16_act", parity=not args.no_cpu_baseline)
+            ref2 = streams_leg(device, rank, weights="bf16_kv", parity=False)
+            leg["fp32_activations_bf16_kv"] = {k: ref2[k] for k in ("utts_per_s", "decode_step_us", "first_chunk_latency_ms", "decode_variant")}
+            leg["fp32_activations_bf16_kv"]["roofline_frac"] = ref2["roofline"]["frac"]
+            out["streams8_bf16_kv"] = leg
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "gvc_gpt_rows_step_launches": (C.c_longlong, [_P]),
     "gvc_gpt_health": (C.c_int, [_P]),
     "gvc_gpt_warmup": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "gvc_gpt_warmup_range": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gvc_gpt_lazy_inits": (C.c_longlong, [_P]),
     "gvc_gpt_rearm": (C.c_int, [_P]),
     "gvc_gpt_time_kernel": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, c_f32p, c_i32p, _P]),
@@ -105,8 +106,19 @@ _SIGNATURES = {
 _lib = None
 
 
+GVC_ERR_TIMEOUT = -5          # include/genvc_hip.h: a hand-off of a one-launch step timed out; repeat the call after resetting the slots
+
+
 class GenvcHipError(RuntimeError):
-    pass
+    """a library call failed; `.code` is its GVC_ERR_* return value (None: raised on the Python side)"""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+    @property
+    def is_handoff_timeout(self):
+        return self.code == GVC_ERR_TIMEOUT
 
 
 def exported_symbols():
@@ -133,7 +145,7 @@ def lib():
 def check(rc, what=""):
     if rc != 0:
         msg = lib().gvc_last_error().decode(errors="replace")
-        raise GenvcHipError(f"{what} failed with code {rc}: {msg}")
+        raise GenvcHipError(f"{what} failed with code {rc}: {msg}", rc)
 
 
 def ptr(t):

@@ -1115,13 +1115,15 @@ static int check_ready(gvc_gpt* c) {
         for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
         c->graphs.clear();
         if (c->r_bufs) (void)hipMemset(c->r_bufs, 0xff, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes());
-        if (c->p_epoch) (void)hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned));
+        // (the step epoch p_epoch[0] stays MONOTONIC: granule tags are (epoch + 1, layer, phase) and nothing zeroes the granules, so an epoch
+        //  that started over could accept a stale granule of the timed-out call; only the arrival counter and the per-XCD ranks are cleared)
+        if (c->p_epoch) (void)hipMemset(c->p_epoch + 1, 0, 15 * sizeof(unsigned));
         *c->seam_err_host = 0;
         c->fallbacks += 1;
         set_error("an in-kernel hand-off of a one-launch decode step timed out (code %d: were all 256 workgroups resident?); the outputs "
                   "of the previous decode / generate / cached-prefill call are invalid.  The context has switched to the launch-per-phase "
                   "paths and stays usable: reset the affected slots and repeat the call", dev_err);
-        return GVC_ERR_STATE;
+        return GVC_ERR_TIMEOUT;
     }
     GVC_REQUIRE(gvc_gpt_missing_weights(c) == 0, GVC_ERR_STATE, "%d GPT weight tensors are not bound",
                 gvc_gpt_missing_weights(c));
@@ -1495,6 +1497,27 @@ extern "C" int gvc_gpt_warmup(gvc_gpt* c, int32_t B, int32_t max_keys, int32_t t
     return GVC_OK;
 }
 
+extern "C" int gvc_gpt_warmup_range(gvc_gpt* c, int32_t B, int32_t min_keys, int32_t max_keys, int32_t top_k) {
+    GVC_REQUIRE(c, GVC_ERR_ARG, "null context");
+    GVC_REQUIRE(min_keys >= 1 && min_keys <= max_keys && max_keys < c->dm.max_seq, GVC_ERR_ARG, "warmup_range: bad key range [%d, %d]", min_keys, max_keys);
+    int rc = gvc_gpt_warmup(c, B, min_keys, top_k);          // (also prepares the one-launch steps: the plans below are then pure look-ups)
+    if (rc) return rc;
+    c->in_warmup = 1;
+    struct Leave { gvc_gpt* c; ~Leave() { c->in_warmup = 0; } } leave{c};
+    int last_key = -1;
+    for (int mk = min_keys; mk <= max_keys; ++mk) {
+        GenPlan pl;
+        if ((rc = plan_generate(c, B, mk, top_k, &pl))) return rc;
+        if (pl.key == last_key) continue;
+        last_key = pl.key;
+        hipGraphExec_t ge;
+        if (step_unroll() > 1 && (rc = step_graph(c, B, pl, step_unroll(), &ge))) return rc;
+        if ((rc = step_graph(c, B, pl, 1, &ge))) return rc;
+    }
+    GVC_CHECK_HIP(hipDeviceSynchronize());
+    return GVC_OK;
+}
+
 extern "C" long long gvc_gpt_lazy_inits(gvc_gpt* c) { return c ? c->lazy_inits : 0; }
 
 // After a hand-off time-out the context runs on the launch-per-phase paths.  That is the right answer while another context holds CUs, and
@@ -1509,7 +1532,7 @@ extern "C" int gvc_gpt_rearm(gvc_gpt* c) {
     for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
     c->graphs.clear();
     if (c->r_bufs) GVC_CHECK_HIP(hipMemset(c->r_bufs, 0xff, c->act_bf16 ? rows_b16_buf_bytes() : rows_buf_bytes()));
-    if (c->p_epoch) GVC_CHECK_HIP(hipMemset(c->p_epoch, 0, 16 * sizeof(unsigned)));
+    if (c->p_epoch) GVC_CHECK_HIP(hipMemset(c->p_epoch + 1, 0, 15 * sizeof(unsigned)));      // (epoch [0] stays monotonic, see check_ready)
     GVC_CHECK_HIP(hipDeviceSynchronize());
     c->persist = c->persist_cfg;
     return GVC_OK;

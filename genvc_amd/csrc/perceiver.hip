@@ -88,6 +88,8 @@ struct gvc_perceiver {
     float *C = nullptr, *kv = nullptr, *X = nullptr, *o = nullptr, *g = nullptr, *xp = nullptr, *work = nullptr, *tmp = nullptr;
     long long work_cap = 0;
     std::map<long long, hipGraphExec_t> graphs;    // (B, F) -> captured body of the forward (context-owned buffers only)
+    std::map<long long, unsigned long long> graph_used;   // (B, F) -> tick of its last replay (eviction: least recently used)
+    unsigned long long tick = 0;
     hipStream_t cap_stream = nullptr, side_stream = nullptr;   // capture: the main chain, and the branch the later layers' context keys / values run on
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int use_graph = 1;               // GVC_PERCEIVER_GRAPH=0: eager launches
@@ -235,8 +237,14 @@ static int perc_prepare(gvc_perceiver* c, hipStream_t s) {
         fm(ly.ff2_w, ly.f_ff2, d, fp);
     }
     GVC_LAUNCH_CHECK();
-    for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);     // (captured with the same buffers, but stay on the safe side)
-    c->graphs.clear();
+    if (!c->graphs.empty()) {
+        // a re-bind: the graphs were captured with the same buffers, but stay on the safe side -- and a replay may still be in flight on
+        // another stream (the conditioning side stream of model_init._CondFuture): wait for the device before destroying them
+        GVC_CHECK_HIP(hipDeviceSynchronize());
+        for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
+        c->graphs.clear();
+        c->graph_used.clear();
+    }
     c->fm_ready = true;
     return GVC_OK;
 }
@@ -355,9 +363,16 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
         const long long key = (long long)B * 100000 + F;
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
-            if (c->graphs.size() >= 32) {          // a long-running caller with ever new reference lengths: keep the cache bounded
-                for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
-                c->graphs.clear();
+            if (c->graphs.size() >= 32) {
+                // a long-running caller with ever new reference lengths: keep the cache bounded by evicting the LEAST RECENTLY USED shape (a
+                // caller that alternates between a few lengths keeps its graphs); the evicted graph may still be replaying on another stream
+                long long victim = c->graphs.begin()->first;
+                for (auto& kvp : c->graph_used)
+                    if (kvp.second < c->graph_used[victim]) victim = kvp.first;
+                GVC_CHECK_HIP(hipDeviceSynchronize());
+                (void)hipGraphExecDestroy(c->graphs[victim]);
+                c->graphs.erase(victim);
+                c->graph_used.erase(victim);
             }
             hipGraph_t graph = nullptr;
             GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -371,6 +386,7 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
             GVC_CHECK_HIP(e);
             it = c->graphs.emplace(key, ge).first;
         }
+        c->graph_used[key] = ++c->tick;
         GVC_CHECK_HIP(hipGraphLaunch(it->second, s));
     }
     hipLaunchKernelGGL(k_rmsnorm_rows_fm16, dim3(cdiv(B * c->dm.num_latents, 4)), dim3(256), 0, s, c->X, out, B * c->dm.num_latents, c->dm.dim,

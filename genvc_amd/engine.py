@@ -144,6 +144,11 @@ class GptEngine:
         """allocations / device syncs / graph captures done inside data-path calls so far (include/genvc_hip.h: gvc_gpt_lazy_inits)"""
         return int(lib().gvc_gpt_lazy_inits(self._h))
 
+    def warmup_range(self, B, min_keys, max_keys, top_k=1):
+        """warm-up of every context class a generation passes through while its longest stream grows from min_keys to max_keys cached
+        positions (include/genvc_hip.h: gvc_gpt_warmup_range -- the library enumerates its own classes)"""
+        check(lib().gvc_gpt_warmup_range(self._h, B, min_keys, max_keys, top_k), "warmup_range")
+
     def rearm(self):
         """back to the one-launch steps after a time-out fallback, when the GPU is the caller's own again (include/genvc_hip.h: gvc_gpt_rearm)"""
         check(lib().gvc_gpt_rearm(self._h), "rearm")

@@ -57,7 +57,22 @@ def _vocode(model, latents):
 
 
 @torch.inference_mode()
-def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=False):
+def _segment_latents(m, cond_latent, codes, gen, repass_latents):
+    """the acoustic latents of one segment's n non-stop tokens.  The reference recomputes them with a second, teacher-forced forward pass
+    over [cond | codes | start, gen, stop x 4] and trims it with `sub = -5` (inference_utils.py:71-76, gpt.py:375-508, :491, :508); row i of
+    that pass is the hidden state that predicted token i -- the very vector the decode loop already produced at step i
+    (stream_generator.py:865; SURVEY.md 8a row 12: equal to <= 4.8e-7).  Default: reuse the decode-time latents of `GPT.generate`
+    (`last_latents`, the EOS-step latent dropped: the re-pass has n rows); `repass_latents=True` runs the reference's second pass."""
+    n = int(gen.shape[-1])
+    if not repass_latents and getattr(m.gpt, "last_latents", None) is not None and m.gpt.last_latents.shape[1] >= n:
+        return m.gpt.last_latents[:1, :n]
+    out_len = torch.tensor([n * m.config.model_args.gpt_code_stride_len], device=m.device)
+    clen = torch.tensor([codes.shape[-1]], device=m.device)
+    return m.gpt(codes, clen, gen.unsqueeze(0), out_len, cond_latents=cond_latent, return_latent=True)
+
+
+@torch.inference_mode()
+def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=False, repass_latents=False):
     """non-streaming conversion, latent-level concatenation (reference :23-89)"""
     m = genVC_mdl
     min_len = int(0.32 * m.content_sample_rate)
@@ -72,9 +87,7 @@ def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=Fa
         gen = gen[gen != m.gpt.stop_audio_token]                        # reference :68 (0-d collapse guarded)
         if gen.numel() == 0:
             continue
-        out_len = torch.tensor([gen.shape[-1] * m.config.model_args.gpt_code_stride_len], device=m.device)
-        clen = torch.tensor([codes.shape[-1]], device=m.device)
-        final_latents.append(m.gpt(codes, clen, gen.unsqueeze(0), out_len, cond_latents=cond_latent, return_latent=True))
+        final_latents.append(_segment_latents(m, cond_latent, codes, gen, repass_latents))
         all_codes.append(gen)
     if not final_latents:                    # every segment ended on its first token: nothing to vocode
         empty = torch.zeros(0, device=m.device)
@@ -87,7 +100,7 @@ def synthesize_utt(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, return_details=Fa
 
 
 @torch.inference_mode()
-def synthesize_utt_chunked(genVC_mdl, src_wav, tgt_audio, seg_len=6.0):
+def synthesize_utt_chunked(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, repass_latents=False):
     """non-streaming conversion with waveform-level concatenation (reference :92-133): every segment goes through
     `genVC_mdl.inference` (trainers/hifigan_trainer.py:457-500) and the segment waveforms are joined by `handle_chunks`
     (1024 samples dropped from each, cross-fade over the previous tail)."""
@@ -101,7 +114,7 @@ def synthesize_utt_chunked(genVC_mdl, src_wav, tgt_audio, seg_len=6.0):
     c = m.config
     for src_seg in segments(src_wav, seg, min_len):
         audio_pred = m.inference(src_seg, cond_latent, top_p=c.top_p, top_k=c.top_k, temperature=c.temperature,
-                                 length_penalty=c.length_penalty, repetition_penalty=c.repetition_penalty)
+                                 length_penalty=c.length_penalty, repetition_penalty=c.repetition_penalty, repass_latents=repass_latents)
         wav_chunk, wav_gen_prev, wav_overlap = handle_chunks(audio_pred.squeeze(), wav_gen_prev, wav_overlap, 1024)
         pred_audios.append(wav_chunk)
     return torch.cat(pred_audios, dim=-1)

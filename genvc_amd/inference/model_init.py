@@ -113,14 +113,10 @@ class GenVCModel(nn.Module):
         top_k = self.config.top_k if top_k is None else top_k
         max_new = int(max_new_tokens or g.max_gen_mel_tokens)
         grp = max(stream_chunk_size, 1)
-        seen = set()
-        for done in range(0, max_new, grp):                  # the calls get_generator / _advance will make: max_keys = n0 + done + n
-            mk = min(n0 + done + grp, eng.dims["max_seq"] - 1)
-            cls = (mk <= 128, mk > 144, mk > 320, mk > 80, mk > 160)      # the context classes the library keys its graphs by
-            if cls in seen:
-                continue
-            seen.add(cls)
-            eng.warmup(streams, mk, top_k)
+        # the calls get_generator / _advance will make reach max_keys = n0 + grp ... n0 + max_new: the library warms every context class in
+        # that range (its thresholds are its own: gvc_gpt_warmup_range)
+        hi = min(n0 + max_new, eng.dims["max_seq"] - 1)
+        eng.warmup_range(streams, min(n0 + grp, hi), hi, top_k)
         if self.hifigan is not None:
             lat = torch.zeros(streams, grp, g.model_dim, device=dev)
             for n in {grp, max(1, max_new % grp)}:
@@ -130,11 +126,12 @@ class GenVCModel(nn.Module):
 
     @torch.no_grad()
     def inference(self, src_audio, cond_latent, do_sample=True, top_p=0.85, top_k=15, temperature=0.75, num_beams=1,
-                  length_penalty=1.0, repetition_penalty=10.0, output_attentions=False):
+                  length_penalty=1.0, repetition_penalty=10.0, output_attentions=False, repass_latents=False):
         """reference trainers/hifigan_trainer.py:457-500: one source segment [1,T] + conditioning latents -> waveform
         [1,1,1024 n]: ContentVec -> content codes -> generate -> strip stop tokens -> latent re-pass -> x4 linear
         interpolation -> HiFi-GAN.  (The reference's 0-d collapse at exactly one non-stop token, SURVEY appendix B.9, is
-        guarded: boolean indexing keeps the dimension.)"""
+        guarded: boolean indexing keeps the dimension.)  The latents are the decode loop's own unless `repass_latents=True`
+        (inference_utils._segment_latents)."""
         feat = self.content_extractor.extract_content_features(src_audio)
         codes = self.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         gen = self.gpt.generate(cond_latent, codes, do_sample=do_sample, top_p=top_p, top_k=top_k, temperature=temperature,
@@ -143,9 +140,8 @@ class GenVCModel(nn.Module):
         gen = gen[gen != self.gpt.stop_audio_token]
         if gen.numel() == 0:
             return torch.zeros(1, 1, 0, device=self.device)
-        out_len = torch.tensor([gen.shape[-1] * self.config.model_args.gpt_code_stride_len], device=self.device)
-        clen = torch.tensor([codes.shape[-1]], device=self.device)
-        lat = self.gpt(codes, clen, gen.unsqueeze(0), out_len, cond_latents=cond_latent, return_latent=True)
+        from genvc_amd.inference.inference_utils import _segment_latents
+        lat = _segment_latents(self, cond_latent, codes, gen, repass_latents)
         mel_input = torch.nn.functional.interpolate(lat.transpose(1, 2), scale_factor=[self.hifigan_scale_factor],
                                                     mode="linear").squeeze(1)
         return self.hifigan.forward(mel_input)

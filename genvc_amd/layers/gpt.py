@@ -134,7 +134,7 @@ class GPT(nn.Module):
         try:
             return fn()
         except GenvcHipError as e:
-            if "timed out" not in str(e):
+            if not e.is_handoff_timeout:
                 raise
             self.recoveries = getattr(self, "recoveries", 0) + 1
             torch.cuda.synchronize()
@@ -474,7 +474,7 @@ class GPT(nn.Module):
                     st = self._start(fake_inputs, generate_kwargs)
                 end = self._advance(st, group)
             except GenvcHipError as e:
-                if "timed out" not in str(e) or retried:
+                if not e.is_handoff_timeout or retried:
                     raise
                 retried = True
                 st = restart()

@@ -24,6 +24,8 @@ that many seconds of its already fed source audio (a multiple of 320 samples, Co
 
 With top_k > 1 the draws differ from a solo run: the counter RNG is keyed by the position in the call, not in the utterance.
 """
+import time
+
 import torch
 
 from .inference.inference_utils import _sampling_kwargs, _vocode, handle_chunks
@@ -46,7 +48,7 @@ class _Session:
 
 
 class StreamSessions:
-    def __init__(self, model, max_sessions=8, group=8, left_context_s=0.0):
+    def __init__(self, model, max_sessions=8, group=8, left_context_s=0.0, rearm_after_s=5.0, rearm_max_tries=3):
         m = self.m = model
         self.ctx = int(round(left_context_s * model.content_sample_rate / 320.0)) * 320       # whole ContentVec hops
         g = m.gpt
@@ -63,7 +65,14 @@ class StreamSessions:
         self.params = sample_params(samp, g.num_audio_tokens, g.stop_audio_token, 0)
         self.calls = 0
         self.recoveries = 0          # decode calls dropped and re-run after a hand-off time-out (gvc_gpt_health)
-        self._rearm = False          # a recovery happened: re-arm the one-launch steps at the next idle moment
+        self._rearm = False          # a recovery happened: the one-launch steps may be re-armed (policy: maybe_rearm)
+        self.rearm_after_s = float(rearm_after_s)
+        self.rearm_max_tries = int(rearm_max_tries)
+        self._rearm_wait = self.rearm_after_s
+        self._rearm_tries = 0        # re-arms since the last clean stretch
+        self._last_timeout = 0.0
+        self.rearms = 0
+        self.rearm_gave_up = False
         self.stop = g.stop_audio_token
         # per-slot history of input ids (fake prefix + generated), as wide as the longest run
         self.width = 32 + g.max_text_tokens + 2 + 1 + self.max_new + 8
@@ -93,17 +102,46 @@ class StreamSessions:
         return s.tokens
 
     def idle(self):
-        idle = all(not s.decoding and not s.queue for s in self.sessions.values())
-        if idle and self._rearm:
-            # a quiet moment after a time-out recovery: nothing of ours is in flight, try the one-launch steps again (if the other context
-            # still holds CUs the next decode call times out once more and is recovered the same way)
-            self._rearm = False
-            try:
-                torch.cuda.synchronize()
-                self.eng.rearm()
-            except GenvcHipError:
-                pass
-        return idle
+        """True when no stream is decoding and nothing is queued (a pure predicate: no device work)"""
+        return all(not s.decoding and not s.queue for s in self.sessions.values())
+
+    def maybe_rearm(self, now=None):
+        """Re-arm policy after a time-out recovery (advisor finding, round 5).  A recovery leaves the context on the launch-per-phase paths,
+        a stable state ~28 % slower.  Going back to the one-launch steps is only worth trying when the GPU is probably ours again, and a
+        failed try is expensive (a ~0.2 s bounded spin, a device sync, graph re-capture, every decoding stream restarted -- with top_k > 1
+        an audible splice), so: only at an idle moment, only after `rearm_after_s` seconds without a time-out, with the wait DOUBLED after
+        every failed try (a try has failed when the next time-out follows it), and never again after `rearm_max_tries` consecutive failed
+        tries (the context then stays on the fallback for good; `rearm_gave_up`).  Called by step() at idle moments; callers that know
+        better (the other process is gone) call it or `eng.rearm()` themselves.  Returns True when it re-armed.  Errors other than a
+        pending time-out propagate."""
+        if not self._rearm or self.rearm_gave_up or not self.idle():
+            return False
+        now = time.monotonic() if now is None else now
+        if now - self._last_timeout < self._rearm_wait:
+            return False
+        self._rearm = False
+        self._rearm_tries += 1
+        torch.cuda.synchronize()
+        try:
+            self.eng.rearm()
+        except GenvcHipError as e:
+            if not e.is_handoff_timeout:
+                raise
+            # a time-out was still pending: the library reported it and stays on the fallback; count it like a failed try
+            self._note_timeout(now)
+            return False
+        self.rearms += 1
+        return True
+
+    def _note_timeout(self, now=None):
+        now = time.monotonic() if now is None else now
+        self._last_timeout = now
+        self._rearm = True
+        if self._rearm_tries > 0:                       # the time-out follows a re-arm: that try failed
+            self._rearm_wait = min(self._rearm_wait * 2.0, 3600.0)
+            if self._rearm_tries >= self.rearm_max_tries:
+                self.rearm_gave_up = True
+        return now
 
     @torch.inference_mode()
     def segment_features(self, ss, wav):
@@ -135,17 +173,18 @@ class StreamSessions:
         stopped; with top_k > 1 the re-run draws with new per-call seeds -- the groups already emitted are skipped, what follows
         comes from a different token sequence (an audible splice is possible)."""
         self._popped = []
+        self.maybe_rearm()           # (a no-op unless a time-out recovery is pending, the scheduler is idle and the back-off has run out)
         try:
             return self._step()
         except GenvcHipError as e:
-            if "timed out" not in str(e):          # (a full KV cache, ... : not recoverable by repeating the work)
+            if not e.is_handoff_timeout:           # (a full KV cache, ... : not recoverable by repeating the work)
                 raise
             self._recover()
             return {}
 
     def _recover(self):
         self.recoveries += 1
-        self._rearm = True
+        self._note_timeout()
         redo = []
         for s in self.sessions.values():
             if s.decoding:

@@ -34,6 +34,10 @@ extern "C" {
 #define GVC_ERR_HIP (-2)          /* a HIP runtime call failed */
 #define GVC_ERR_STATE (-3)        /* weights missing, cache overflow, wrong call order */
 #define GVC_ERR_UNSUPPORTED (-4)  /* dimension not supported by the kernels */
+#define GVC_ERR_TIMEOUT (-5)      /* a hand-off of a one-launch step timed out (not all 256 workgroups resident): the previous decode / generate /
+                                     cached-prefill call produced garbage; the context has switched to the launch-per-phase paths and stays usable --
+                                     reset the affected slots and repeat the call (gvc_gpt_health).  Distinct from GVC_ERR_STATE (a full KV cache,
+                                     missing weights), which repeating does not cure */
 
 typedef void* gvc_stream;         /* hipStream_t */
 
@@ -166,7 +170,7 @@ int gvc_sample(const float* logits, int32_t B, int32_t* ids, int32_t ids_stride,
  * + bf16 KV cache; d_model 1024 or 512 for the bf16 modes) and the step of 2..16 streams runs its whole block stack in ONE launch
  * (csrc/persist_rows.h; d_model 1024, 4 heads of 256, an even layer count); other shapes and batch sizes take the
  * launch-per-phase paths.  A hand-off of a one-launch step that times out (not all of its 256 workgroups resident: another
- * process or stream holds CUs) is reported ONCE -- by gvc_gpt_health, else by the next call -- as GVC_ERR_STATE, and the context
+ * process or stream holds CUs) is reported ONCE -- by gvc_gpt_health, else by the next call -- as GVC_ERR_TIMEOUT, and the context
  * continues on the launch-per-phase paths (see gvc_gpt_health).  Eight consecutive steps are captured per graph.
  * ------------------------------------------------------------------------------------------ */
 int gvc_gpt_generate(gvc_gpt* ctx, const int32_t* slots, int32_t B, int32_t* ids, int32_t ids_stride,
@@ -186,7 +190,7 @@ long long gvc_gpt_rows_step_launches(gvc_gpt* ctx);
 /* Health of the work a caller has just synchronised (no reference counterpart: the reference has no in-kernel hand-offs).  The
  * one-launch steps need all 256 workgroups co-resident; when another process or stream holds CUs a hand-off times out (~0.2 s,
  * bounded spins), the step's outputs are garbage and a device-visible word records it.  This call -- and, failing that, the next
- * library call -- then returns GVC_ERR_STATE ONCE, having switched the context to the launch-per-phase paths (captured graphs
+ * library call -- then returns GVC_ERR_TIMEOUT ONCE, having switched the context to the launch-per-phase paths (captured graphs
  * dropped, hand-off buffers re-initialised): the context stays usable, the caller resets the affected slots and repeats the work.
  * Also reports a full KV cache / mel position table (see gvc_gpt_reset_slots).  GVC_OK otherwise. */
 int gvc_gpt_health(gvc_gpt* ctx);
@@ -198,6 +202,10 @@ int gvc_gpt_health(gvc_gpt* ctx);
  * Afterwards gvc_gpt_generate / gvc_gpt_decode_step / gvc_gpt_prefill_cached calls of that shape do no hipMalloc, no
  * hipDeviceSynchronize and no graph capture. */
 int gvc_gpt_warmup(gvc_gpt* ctx, int32_t B, int32_t max_keys, int32_t top_k);
+/* The same for EVERY context class a generation over B streams passes through while its longest stream grows from min_keys to max_keys
+ * cached positions (the library keys its step graphs by classes of the context length -- fused / split-key attention, 1 / 2 / 4 key chunks
+ * of the rows steps -- whose thresholds are its own business: callers name the range, not the classes). */
+int gvc_gpt_warmup_range(gvc_gpt* ctx, int32_t B, int32_t min_keys, int32_t max_keys, int32_t top_k);
 /* Diagnostic: allocations / device-wide synchronisations / graph captures this context has done INSIDE data-path calls (first use
  * of a path that gvc_gpt_warmup had not prepared; a rebind after the weight pack was built; the fallback after a hand-off
  * time-out).  gvc_gpt_warmup's own work does not count.  Tests assert it stays put across warmed-up calls. */

@@ -303,7 +303,7 @@ def test_one_shot_harnesses_recover_from_a_hand_off_timeout(monkeypatch):
     def flaky():
         state["n"] += 1
         if state["n"] in state["fail_at"]:
-            raise GenvcHipError("health: injected -- an in-kernel hand-off of a one-launch decode step timed out")
+            raise GenvcHipError("health: injected -- an in-kernel hand-off of a one-launch decode step timed out", -5)
         real()
     m.gpt.engine.health = flaky
     got = synthesize_utt_streaming(m, src, ref, seg_len=1.0, stream_chunk_size=8, verbose=False, return_details=True)
@@ -386,13 +386,13 @@ def test_stream_sessions_recover_when_the_time_out_surfaces_at_a_later_call(monk
     def prefill(*a, **k):
         calls["prefill"] += 1
         if calls["prefill"] == 3:
-            raise GenvcHipError("prefill: injected -- an in-kernel hand-off of a one-launch decode step timed out")
+            raise GenvcHipError("prefill: injected -- an in-kernel hand-off of a one-launch decode step timed out", -5)
         return real_prefill(*a, **k)
 
     def generate(*a, **k):
         calls["generate"] += 1
         if calls["generate"] == 9:
-            raise GenvcHipError("generate: injected -- an in-kernel hand-off of a one-launch decode step timed out")
+            raise GenvcHipError("generate: injected -- an in-kernel hand-off of a one-launch decode step timed out", -5)
         return real_generate(*a, **k)
     eng.prefill, eng.generate = prefill, generate
     sids = [ss.open(r) for r in refs]

@@ -180,3 +180,73 @@ def test_rows_step_bf16_activations_vs_oracle(L, B, Tc, n, H):
         bad = (~agree[b]).nonzero()
         if len(bad):
             assert float(margins[b, int(bad[0])]) < 1e-2, (b, int(bad[0]), float(margins[b, int(bad[0])]))
+
+
+@pytest.mark.parametrize("tiny", [True, False], ids=["tiny", "full_size_6s_segment"])
+def test_non_streaming_paths_reuse_the_decode_latents(tiny):
+    """reference inference/inference_utils.py:68-76 recomputes a segment's latents with a second forward pass (gpt.py:375-508, trimmed with
+    sub = -5, :491, :508); row i of that pass is the hidden state that predicted token i, i.e. the vector the decode loop produced at step i
+    (stream_generator.py:865).  The harnesses reuse those by default (the EOS-step latent dropped); `repass_latents=True` runs the reference's
+    pass: same tokens, latents and waveform <= 1e-4 apart -- synthesize_utt, synthesize_utt_chunked and GenVCModel.inference, with a
+    max_length ending (no stop token: n rows) and a 6 s segment at full size (141 steps, contexts 110 -> 251)."""
+    from genvc_amd.inference.inference_utils import synthesize_utt, synthesize_utt_chunked
+    m = _model(tiny, 3 if tiny else 1, max_new=37 if tiny else 141)
+    seg = 1.0 if tiny else 6.0
+    src = synth.synth_audio(7, "src", 40000 if tiny else 96000)            # tiny: 1 s + 1 s + 0.5 s; full: one 6 s segment
+    ref = synth.synth_audio(8, "ref", 72000)
+    a = synthesize_utt(m, src, ref, seg_len=seg, return_details=True)
+    b = synthesize_utt(m, src, ref, seg_len=seg, return_details=True, repass_latents=True)
+    assert all(torch.equal(x, y) for x, y in zip(a["codes"], b["codes"]))
+    assert a["latents"].shape == b["latents"].shape
+    np.testing.assert_allclose(a["latents"].cpu().numpy(), b["latents"].cpu().numpy(), atol=1e-4)
+    np.testing.assert_allclose(a["wav"].cpu().numpy(), b["wav"].cpu().numpy(), atol=1e-4)
+    if tiny:
+        ca = synthesize_utt_chunked(m, src, ref, seg_len=seg)
+        cb = synthesize_utt_chunked(m, src, ref, seg_len=seg, repass_latents=True)
+        np.testing.assert_allclose(ca.cpu().numpy(), cb.cpu().numpy(), atol=1e-4)
+        # an EOS ending: the stop token is stripped, the EOS-step latent is not used
+        with torch.inference_mode():
+            m.gpt.mel_head.bias[1025] = 1.8
+        m.gpt.init_gpt_for_inference()
+        m.gpt.max_gen_mel_tokens = 37
+        a = synthesize_utt(m, src, ref, seg_len=seg, return_details=True)
+        b = synthesize_utt(m, src, ref, seg_len=seg, return_details=True, repass_latents=True)
+        assert a["latents"].shape == b["latents"].shape and a["latents"].shape[1] == sum(int(c.numel()) for c in a["codes"])
+        np.testing.assert_allclose(a["latents"].cpu().numpy(), b["latents"].cpu().numpy(), atol=1e-4)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_rearm_after_a_single_failed_step_never_accepts_stale_granules(monkeypatch):
+    """advisor finding (round 5): the one-stream step accepts a granule when its tag is (epoch + 1, layer, phase) and relies on a MONOTONIC
+    epoch because nothing zeroes the granules.  The fallback / re-arm used to reset the epoch: if the timed-out call was a single decode step
+    at epoch 0 (right after create), its granules kept the very tags the first re-armed step expects.  Now the epoch is never reset: a
+    single failed decode_step, the fallback, a re-arm, then the one-launch step must give the oracle's ids (GVC_ERR_TIMEOUT is its own code)."""
+    from genvc_amd._lib import GenvcHipError, GVC_ERR_TIMEOUT
+    from genvc_amd.engine import GptEngine
+    from test_gpu_gpt import run_generate
+    from oracle import genvc_oracle as O
+    torch.cuda.empty_cache()
+    dims = gcfg.gpt_dims(dict(gcfg.DEFAULT_MODEL_ARGS, gpt_layers=2))
+    w = synth.make_weights(3, synth.gpt_weight_spec(dims), device=DEV)
+    eng = GptEngine(dims, max_slots=4, max_rows=2048)
+    eng.bind(w)
+    cond = synth.uniform(300, "cond_latents", (1, 32, 1024), 1.0)
+    codes = synth.integers(300, "content_codes", (1, 13), 256)
+    n = 16
+    ref_t, _, _ = O.generate({k: v.cpu() for k, v in w.items()}, dims, cond, codes, GREEDY, max_new=n, stop_on_eos=False)
+    slots = torch.zeros(1, device=DEV, dtype=torch.int32)
+    eng.prefill(slots, eng.prefix_embeddings(cond.to(DEV), codes.to(DEV).int()), want_outputs=False)
+    monkeypatch.setenv("GVC_PERSIST_TEST_GRID", "255")
+    eng.decode_step(slots, torch.tensor([5], device=DEV, dtype=torch.int32))          # ONE step, at epoch 0: every hand-off times out
+    torch.cuda.synchronize()
+    with pytest.raises(GenvcHipError) as ei:
+        eng.health()
+    assert ei.value.code == GVC_ERR_TIMEOUT and ei.value.is_handoff_timeout
+    monkeypatch.delenv("GVC_PERSIST_TEST_GRID")
+    eng.reset(slots)
+    eng.rearm()
+    _, toks, _ = run_generate(eng, dims, cond, codes, n)
+    assert eng.decode_variant() == 3, "not back on the one-launch step"
+    assert torch.equal(toks.long(), ref_t), "the first re-armed steps accepted stale hand-off values"
+    eng.close()

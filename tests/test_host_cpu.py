@@ -504,3 +504,46 @@ def test_convert_offline_world8_equals_world1_for_64_utterances():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got.shape == one.shape and np.array_equal(got, one)
+
+
+def test_stream_sessions_rearm_policy_backs_off_and_gives_up():
+    """advisor finding (round 5): StreamSessions used to re-arm the one-launch steps at EVERY idle moment after a time-out recovery -- under
+    persistent contention a loop of time-out, recovery, idle, re-arm.  Now idle() is a pure predicate and maybe_rearm() re-arms only at an
+    idle moment, only after `rearm_after_s` quiet seconds, doubles the wait after every failed try and stops after `rearm_max_tries`."""
+    from genvc_amd.streaming import StreamSessions
+
+    class Eng:
+        def __init__(self):
+            self.rearmed = 0
+
+        def rearm(self):
+            self.rearmed += 1
+
+    import torch
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        ss = object.__new__(StreamSessions)
+        ss.sessions, ss.eng = {}, Eng()
+        ss._rearm, ss.rearm_gave_up, ss.rearm_after_s, ss.rearm_max_tries = False, False, 5.0, 3
+        ss._rearm_wait, ss._rearm_tries, ss._last_timeout, ss.rearms, ss.recoveries = 5.0, 0, 0.0, 0, 0
+        assert ss.idle() and not ss.maybe_rearm(now=100.0)          # nothing pending
+        ss._note_timeout(now=100.0)                                 # first time-out
+        assert not ss.maybe_rearm(now=102.0)                        # too early
+        assert ss.maybe_rearm(now=105.5) and ss.eng.rearmed == 1    # after 5 quiet seconds
+        ss._note_timeout(now=106.0)                                 # ... which failed: the wait doubles
+        assert ss._rearm_wait == 10.0 and not ss.maybe_rearm(now=112.0)
+        assert ss.maybe_rearm(now=116.5) and ss.eng.rearmed == 2
+        ss._note_timeout(now=117.0)
+        assert ss._rearm_wait == 20.0 and ss.maybe_rearm(now=140.0) and ss.eng.rearmed == 3
+        ss._note_timeout(now=141.0)                                 # the third failed try: stay on the fallback for good
+        assert ss.rearm_gave_up and not ss.maybe_rearm(now=10000.0) and ss.eng.rearmed == 3
+        # a busy scheduler never re-arms
+        ss.rearm_gave_up, ss._rearm = False, True
+
+        class S:
+            decoding, queue = True, []
+        ss.sessions = {0: S()}
+        assert not ss.idle() and not ss.maybe_rearm(now=20000.0)
+    finally:
+        torch.cuda.synchronize = real_sync
