@@ -197,9 +197,11 @@ def cpu_baseline(wl, budget_s=10.0, gpu=None):
     codes0 = torch.zeros(1, 13, dtype=torch.long)
     best = None
     sweep = []
-    for nt in sorted({8, 16, 32, 64, os.cpu_count() or 8}):
+    for nt in sorted({8, 16, 32, 64, min(os.cpu_count() or 8, 128)}):      # (all 256 hardware threads of the GPU box's host: 150 s for three steps)
         if nt > (os.cpu_count() or 8):
             continue
+        if best is not None and sweep[-1]["seconds_prefill48_plus_2_steps"] > 3.0 * best[0]:
+            break                                     # past the knee: more threads only get slower
         torch.set_num_threads(nt)
         t0 = time.time()
         O.generate(w, dims, cond0, codes0, greedy, max_new=3, stop_on_eos=False)

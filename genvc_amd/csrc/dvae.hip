@@ -148,8 +148,8 @@ struct gvc_dvae {
     long long work_cap = 0;
     // one-round-trip conv path (conv_lds.h; every conv's input channels a multiple of 256, as at the reference size): every conv
     // output has its own buffer, so the zero rows either side of the live region are never written (no k_zero_pad_rows launches)
-    bool lds_path = false;               // GVC_DVAE_CONV_LDS=0: the tiled GEMM for every conv
-    int lds_rows = 600;                  // GVC_DVAE_CONV_LDS_ROWS: calls with more than this many input frames (B x T) stay on the tiled GEMM
+    bool lds_path = false;               // streaming-sized calls: every conv on k_conv_lds
+    int lds_rows = 600;                  // calls with more than this many input frames (B x T) stay on the tiled GEMM
     std::vector<float*> lbuf;            // [num_layers] stage outputs (the last one is updated in place by the ResBlocks) + 2 ResBlock temporaries
     int* cnt = nullptr;                  // arrival counters of the K-split convs
     int cur_T = -1, cur_B = -1;
@@ -200,8 +200,7 @@ extern "C" int gvc_dvae_create(const gvc_dvae_dims* dims, gvc_dvae** out) {
     c->work_cap = 4ll << 20;
     if (!rc) rc = dalloc(c, &c->work, (size_t)c->work_cap);
     // the k_conv_lds path: every conv in 256-channel slices
-    c->lds_path = !(getenv("GVC_DVAE_CONV_LDS") && atoi(getenv("GVC_DVAE_CONV_LDS")) == 0);
-    if (getenv("GVC_DVAE_CONV_LDS_ROWS")) c->lds_rows = atoi(getenv("GVC_DVAE_CONV_LDS_ROWS"));
+    c->lds_path = true;
     {
         std::vector<ConvW*> all;
         for (ConvW& w : c->down) all.push_back(&w);

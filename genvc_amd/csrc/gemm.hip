@@ -118,8 +118,7 @@ int launch_gemm_cap(GemmArgs G, int batch, long long work_cap, hipStream_t s) {
     const int tm = cdiv(G.M, BM), tn = cdiv(G.N, BN);
     const long long tiles = (long long)tm * tn * batch;
     int SK = 1;
-    static const int sk_tiles = getenv("GVC_GEMM_SK_TILES") ? atoi(getenv("GVC_GEMM_SK_TILES")) : 128;
-    static const int sk_target = getenv("GVC_GEMM_SK_TARGET") ? atoi(getenv("GVC_GEMM_SK_TARGET")) : 192;
+    constexpr int sk_tiles = 128, sk_target = 192;       // split K below this many tiles / towards this many workgroups
     if (tiles < sk_tiles && G.work) {
         SK = (int)((sk_target + tiles - 1) / tiles);
         const int max_by_k = G.K / (4 * BK) > 0 ? G.K / (4 * BK) : 1;
@@ -508,11 +507,15 @@ __global__ __launch_bounds__(64) void k_ln_sum_rows_t(const float* x_in, float* 
 
 int launch_ln_sum_rows(const float* x_in, float* x_out, float* a, const float* part, int SK, const float* bias, int rows, int d,
                        const float* ln_w, const float* ln_b, int a_fm16, hipStream_t s) {
-    GVC_REQUIRE(d % 256 == 0 && d >= 256 && d <= 1024 && SK >= 0 && SK <= 8, GVC_ERR_UNSUPPORTED, "ln_sum_rows: d=%d SK=%d unsupported", d, SK);
-    if (d == 1024) hipLaunchKernelGGL(k_ln_sum_rows_t<4>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
-    else if (d == 768) hipLaunchKernelGGL(k_ln_sum_rows_t<3>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
-    else if (d == 512) hipLaunchKernelGGL(k_ln_sum_rows_t<2>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
-    else hipLaunchKernelGGL(k_ln_sum_rows_t<1>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);
+    GVC_REQUIRE(d % 256 == 0 && d >= 256 && d <= 2048 && SK >= 0 && SK <= 8, GVC_ERR_UNSUPPORTED, "ln_sum_rows: d=%d SK=%d unsupported", d, SK);
+#define GVC_LN_SUM(nv)                                                                                                                      \
+    case nv:                                                                                                                                \
+        hipLaunchKernelGGL(k_ln_sum_rows_t<nv>, dim3(rows), dim3(64), 0, s, x_in, x_out, a, part, SK, bias, rows, ln_w, ln_b, a_fm16);       \
+        break;
+    switch (d / 256) {
+        GVC_LN_SUM(1) GVC_LN_SUM(2) GVC_LN_SUM(3) GVC_LN_SUM(4) GVC_LN_SUM(5) GVC_LN_SUM(6) GVC_LN_SUM(7) GVC_LN_SUM(8)
+    }
+#undef GVC_LN_SUM
     GVC_LAUNCH_CHECK();
     return GVC_OK;
 }
@@ -841,7 +844,7 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
     if (sk_max > 8) sk_max = 8;
     int best_w = 0, best_sk = 1;
     double best = 1e30;
-    static const double fill = getenv("GVC_STRIP_FILL") ? atof(getenv("GVC_STRIP_FILL")) : 40.0;
+    constexpr double fill = 40.0;                        // the cost model's pipeline-fill term
     for (int w = 1; w <= 9; ++w) {
         const int MG = cdiv(S.mt, w);
         if (cdiv(S.mt, MG) != w) continue;              // the balanced partition's largest group: only exact fits are candidates
@@ -853,13 +856,6 @@ int launch_gemm_strip(GemmArgs G, int sk_max, long long work_cap, int raw_partia
             const double serial = (double)cdiv((int)wgs, 256) * w * cdiv(S.kb, sk);
             const double cost = serial + fill * cdiv((int)wgs, 256 * wpc) + (sk > 1 && !raw_partials ? 30.0 : 0.0);
             if (cost < best) { best = cost; best_w = w; best_sk = sk; }
-        }
-    }
-    static const char* ov = getenv("GVC_STRIP");
-    if (ov) {
-        int w = 0, sk = 0;
-        if (sscanf(ov, "%d,%d", &w, &sk) == 2 && w >= 1 && w <= 9 && sk >= 1 && sk <= sk_max && (sk == 1 || (long long)sk * G.M * G.N <= work_cap)) {
-            best_w = cdiv(S.mt, cdiv(S.mt, w)); best_sk = sk;
         }
     }
     GVC_REQUIRE(best_w > 0, GVC_ERR_ARG, "strip gemm: no geometry for M=%d N=%d K=%d", G.M, G.N, G.K);
@@ -928,21 +924,9 @@ extern "C" int gvc_gemm_probe(int32_t variant, const float* A, const float* W, c
         hipLaunchKernelGGL(k_to_fm16, dim3(1024), dim3(256), 0, s, W, Wf, N, K);
         G.A = Af; G.lda = K; G.Wt = Wf; G.ldw = K;
     }
-    // GVC_PROBE_COLD=n (skinny): n copies of the weights, a different one per launch (n x N x K x 4 bytes beyond the 256 MB memory-side
-    // cache = weights from HBM, as in a layer stack: 3-4 us more than the warm loop at 48 rows)
-    const int ncold = variant == 2 && getenv("GVC_PROBE_COLD") ? atoi(getenv("GVC_PROBE_COLD")) : 0;
-    float* Wcold = nullptr;
-    struct ColdFree { float** p; ~ColdFree() { if (*p) (void)hipFree(*p); } } cold_free{&Wcold};
-    if (ncold > 0) {
-        GVC_CHECK_HIP(hipMalloc((void**)&Wcold, (size_t)ncold * N * K * sizeof(float)));
-        for (int i = 0; i < ncold; ++i)
-            GVC_CHECK_HIP(hipMemcpyAsync(Wcold + (size_t)i * N * K, Wf, (size_t)N * K * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-    int it_no = 0;
     auto once = [&]() -> int {
         if (variant == 0) return launch_gemm_cap(G, 1, work_cap, s);
         if (variant == 1) return launch_gemm_strip(G, sk_max, work_cap, 0, nullptr, s);
-        if (ncold > 0) G.Wt = Wcold + (size_t)(it_no++ % ncold) * N * K;
         return launch_gemm_skinny(G, 1, work_cap, s);
     };
     int rc = once();

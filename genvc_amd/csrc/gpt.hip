@@ -236,13 +236,13 @@ struct gvc_gpt {
     float *x = nullptr, *a = nullptr, *q = nullptr, *h = nullptr, *part = nullptr, *work = nullptr;
     long long work_cap = 0;
     float *x2 = nullptr, *part2 = nullptr;        // fused attention path: second residual buffer, per-head partials
-    int fuse_decode = 1;                          // GVC_FUSE_ATTN=0 disables k_attn_proj
+    int fuse_decode = 1;                          // the fused attention + c_proj launch (k_attn_proj) serves short one-stream contexts
     int* seam_err_host = nullptr;                 // pinned, device-visible: a timed-out hand-off of the one-launch step / a full KV cache
     int* seam_err_dev = nullptr;
-    int skinny_prefill = 1;                       // GVC_SKINNY_PREFILL=0: always the tiled GEMM
-    int strip_prefill = 1;                        // GVC_STRIP_PREFILL=0: more than 128 rows go to the tiled GEMM
-    int fuse_ln_rows = 8;                         // GVC_FUSE_LN_ROWS: the prologue variant serves up to this many rows (<= 16)
-    int fuse_ln = 1;                              // GVC_FUSE_LN=0: LayerNorm launches always stay separate on the skinny path
+    int skinny_prefill = 1;                       // fragment-major weight copies + skinny / strip GEMMs (0 only when their allocation failed)
+    int strip_prefill = 1;                        // more than 128 rows: strip GEMM
+    int fuse_ln_rows = 8;                         // the LayerNorm-prologue GEMM serves up to this many rows (9+: separate launches win)
+    int fuse_ln = 1;
     float* xalt = nullptr;                        // second residual buffer of that path [16][d]
     int rows_decode_min = 5;                      // batches of at least this many streams decode on the MFMA rows path (0: never);
                                                   // measured crossover: B=4 925 (GEMV) vs 975 us (rows), B=5 1242 vs 996 us
@@ -271,7 +271,7 @@ struct gvc_gpt {
     int persist_cfg = 1;              // what GVC_PERSIST allowed at create (gvc_gpt_rearm restores it)
     // one-launch block stack for 2..16 rows (persist_rows.h): batched decode steps, cached chunk prefills
     int persist_rows = 1;             // GVC_PERSIST_ROWS=0: those calls keep the launch-per-phase rows path
-    int persist_rows_min = 2;         // GVC_PERSIST_ROWS_MIN: smallest row count served
+    int persist_rows_min = 2;         // smallest row count the one-launch rows step serves
     long long r_launches = 0;         // one-launch rows steps issued (gvc_gpt_rows_step_launches; graph replays count once per capture)
     int r_ready = 0;                  // 0 not prepared yet, 1 ready, -1 unavailable on this device / for these dims
     RowsLayer* r_layers = nullptr;
@@ -282,7 +282,6 @@ struct gvc_gpt {
     std::vector<char> r_dirty;         // per layer: a matrix was re-bound after the pack was built (gvc_gpt_bind_weight) -> repack before use
     size_t r_lds = 0;
     int rows_keys_hint = 0;           // cached positions the longest stream of the running call reaches (set by the entry points)
-    int r_split1 = 0, r_split2 = 0;    // GVC_ROWS_PERSIST_SPLIT: cached positions from which the keys of a (row, head) take 2 / 4 workgroups
     int p_xl = 1;                     // the one-stream step keeps the MLP's hidden units inside their XCD (GVC_PERSIST_XCD=0: never); cleared by
                                       // persist_prepare when the device does not deal a 256-workgroup grid as 8 XCDs x 32
     int arch_xcc = 0;                 // gcnArchName is gfx94x / gfx950: HW_REG_XCC_ID exists and means what the XL layout assumes
@@ -303,8 +302,12 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_REQUIRE(D.n_layer > 0 && D.n_head > 0 && D.d_model % D.n_head == 0, GVC_ERR_ARG, "bad GPT dims");
     const int hd = D.d_model / D.n_head;
     // the decode GEMVs keep a whole residual row in one wave (d / 256 float4 per lane): d = 256, 512, 768 or 1024
-    GVC_REQUIRE(D.d_model % 256 == 0 && D.d_model >= 256 && D.d_model <= 1024, GVC_ERR_UNSUPPORTED,
-                "d_model %d unsupported (a multiple of 256 up to 1024)", D.d_model);
+    // widths above 1024 (the reference takes every dimension from the checkpoint's config: inference/model_init.py:11-12,
+    // configs/genVC_configs.py:127-139) run on the GEMM paths only -- prefill and decode alike as rows through the skinny / strip / tiled
+    // GEMMs with separate LayerNorm launches, the head as a LayerNorm launch + a GEMM; the GEMV decode kernels and the one-launch steps
+    // keep a residual row in one wave and stay at <= 1024
+    GVC_REQUIRE(D.d_model % 256 == 0 && D.d_model >= 256 && D.d_model <= 2048, GVC_ERR_UNSUPPORTED,
+                "d_model %d unsupported (a multiple of 256 up to 2048)", D.d_model);
     GVC_REQUIRE(hd == 64 || hd == 128 || hd == 256, GVC_ERR_UNSUPPORTED, "head_dim %d unsupported (64, 128 or 256)", hd);
     GVC_REQUIRE(D.max_slots >= 1 && D.max_slots <= 64, GVC_ERR_ARG, "max_slots must be in [1,64]");
     GVC_REQUIRE(D.max_rows >= D.max_slots, GVC_ERR_ARG, "max_rows must be >= max_slots");
@@ -338,10 +341,6 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
         ly.fc_w = take(4 * d * d); ly.fc_b = take(4 * d); ly.p2_w = take(4 * d * d); ly.p2_b = take(d);
     }
     c->n_expected = 10 + 12 * (int)L;
-    if (getenv("GVC_SKINNY_PREFILL")) c->skinny_prefill = atoi(getenv("GVC_SKINNY_PREFILL"));
-    if (getenv("GVC_FUSE_LN")) c->fuse_ln = atoi(getenv("GVC_FUSE_LN"));
-    if (getenv("GVC_FUSE_LN_ROWS")) c->fuse_ln_rows = std::min(16, std::max(1, atoi(getenv("GVC_FUSE_LN_ROWS"))));
-    if (getenv("GVC_STRIP_PREFILL")) c->strip_prefill = atoi(getenv("GVC_STRIP_PREFILL"));
     gemm_init_attributes();
     GVC_CHECK_HIP(hipMalloc((void**)&c->xalt, (size_t)16 * d * sizeof(float)));
     if (getenv("GVC_ROWS_DECODE_MIN")) c->rows_decode_min = atoi(getenv("GVC_ROWS_DECODE_MIN"));
@@ -392,15 +391,12 @@ extern "C" int gvc_gpt_create(const gvc_gpt_dims* dims, gvc_gpt** out) {
     GVC_CHECK_HIP(hipMalloc((void**)&c->gen_call, sizeof(GenCall)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     if ((rc = gemv_init())) { gvc_gpt_destroy(c); return rc; }
-    if (getenv("GVC_FUSE_ATTN")) c->fuse_decode = atoi(getenv("GVC_FUSE_ATTN"));
     GVC_CHECK_HIP(hipHostMalloc((void**)&c->seam_err_host, sizeof(int), hipHostMallocMapped));
     *c->seam_err_host = 0;
     GVC_CHECK_HIP(hipHostGetDevicePointer((void**)&c->seam_err_dev, c->seam_err_host, 0));
     if (getenv("GVC_PERSIST")) c->persist = atoi(getenv("GVC_PERSIST"));
     c->persist_cfg = c->persist;
     if (getenv("GVC_PERSIST_ROWS")) c->persist_rows = atoi(getenv("GVC_PERSIST_ROWS"));
-    if (getenv("GVC_PERSIST_ROWS_MIN")) c->persist_rows_min = std::max(2, atoi(getenv("GVC_PERSIST_ROWS_MIN")));
-    if (getenv("GVC_ROWS_PERSIST_SPLIT")) sscanf(getenv("GVC_ROWS_PERSIST_SPLIT"), "%d,%d", &c->r_split1, &c->r_split2);
     if (getenv("GVC_DEBUG_STAMPS")) {
         GVC_CHECK_HIP(hipMalloc((void**)&c->dbg, 4096 * 8 * sizeof(unsigned long long)));
         GVC_CHECK_HIP(hipMemset(c->dbg, 0, 4096 * 8 * sizeof(unsigned long long)));
@@ -528,8 +524,7 @@ static int gemv_geom(const gvc_gpt* c, int N, int K, GemvGeom* g) {
     g->ksplit = K / (g->NI * 256);
     GVC_REQUIRE(g->ksplit * g->NI * 256 == K && g->ksplit <= 8, GVC_ERR_UNSUPPORTED, "gemv: K=%d unsupported", K);
     const int items = N * g->ksplit;
-    static const int wpb_split = getenv("GVC_WPB_SPLIT") ? atoi(getenv("GVC_WPB_SPLIT")) : 12;
-    static const int blocks_per_cu = getenv("GVC_BLOCKS_PER_CU") ? atoi(getenv("GVC_BLOCKS_PER_CU")) : 1;
+    constexpr int wpb_split = 12, blocks_per_cu = 1;        // (swept in round 1: profiles/r01_microbench_notes.md)
     int wpb = cdiv(items, blocks_per_cu * c->n_cu);
     if (wpb > wpb_split) wpb = cdiv(items, 2 * blocks_per_cu * c->n_cu);
     if (wpb < 4) wpb = 4;
@@ -660,7 +655,7 @@ static inline bool prof_skip(const gvc_gpt* c, int which) {
 // can the fused attention + c_proj launch serve this call?  one stream, head_dim 256, and the caller
 // guarantees at most 8 * kFusedMaxKeys cached positions for the whole run (gvc_gpt_generate: ids_stride)
 static bool fused_ok(const gvc_gpt* c, int B, int max_keys) {
-    return c->fuse_decode && B == 1 && c->hd == 256 && c->dm.d_model % 16 == 0 && max_keys <= 8 * kFusedMaxKeys;
+    return c->fuse_decode && B == 1 && c->hd == 256 && c->dm.d_model % 16 == 0 && c->dm.d_model <= 1024 && max_keys <= 8 * kFusedMaxKeys;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -730,8 +725,6 @@ static bool xcd_topology_ok(gvc_gpt* c) {
     }
     if (hist) (void)hipFree(hist);
     (void)hipGetLastError();
-    if (getenv("GVC_PERSIST_PROBE_DEBUG"))
-        fprintf(stderr, "xcd probe: ok %d, per-XCD %u %u %u %u %u %u %u %u, arrived %u, gave up %u\n", (int)ok, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
     if (!ok || h[9] != 0 || h[8] != (unsigned)kPG) return false;
     for (int x = 0; x < 8; ++x)
         if (h[x] != (unsigned)kPG / 8) return false;
@@ -824,17 +817,6 @@ static int launch_persist(gvc_gpt* c, const int32_t* slots, const int32_t* tok_i
     A.logits_out = logits_out; A.latent_out = latent_out; A.step_ctr = step_ctr; A.advance = 1;
     A.gran = c->p_gran; A.epoch = c->p_epoch; A.err = c->seam_err_dev; A.ring_slots = c->p_ring_slots; A.ascr_floats = c->p_ascr; A.hvec_floats = c->p_hvec;
     A.dbg = c->p_dbg;
-    static const int poll_b = getenv("GVC_PERSIST_POLL_B") ? atoi(getenv("GVC_PERSIST_POLL_B")) : 3;
-    static const int poll_h = getenv("GVC_PERSIST_POLL_H") ? atoi(getenv("GVC_PERSIST_POLL_H")) : 3;
-    // fills in flight per loader wave: ONE is enough to keep up (11 KB/us per CU) and leaves the memory queue to the consumers' polls
-    // (round 4, with the XCD-local hand-off: 528-530 us per step against 530-533 with two, 547 against 554 at 110-174 keys; three: 554)
-    static const int loader_depth = getenv("GVC_PERSIST_LOADER_DEPTH") ? atoi(getenv("GVC_PERSIST_LOADER_DEPTH")) : 1;
-    static const int ln_one_pass = getenv("GVC_PERSIST_LN_ONE_PASS") ? atoi(getenv("GVC_PERSIST_LN_ONE_PASS")) : 0;
-    A.poll_b = poll_b; A.poll_h = poll_h; A.loader_depth = loader_depth; A.ln_one_pass = ln_one_pass;
-    static const int dbg_layer = getenv("GVC_PERSIST_STAMP_LAYER") ? atoi(getenv("GVC_PERSIST_STAMP_LAYER")) : 2;
-    A.dbg_layer = dbg_layer;
-    static const int nosent = getenv("GVC_PERSIST_NOSENT") ? atoi(getenv("GVC_PERSIST_NOSENT")) : 0;
-    A.nosent = nosent;
     if (c->bf16) A.head_w = reinterpret_cast<const float*>(c->head_h);
     void* kargs[] = {&A};
     GVC_CHECK_HIP(hipLaunchKernel((const void*)persist_kernel(c), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->p_lds, s));
@@ -984,18 +966,10 @@ static int launch_rows_persist(gvc_gpt* c, const int32_t* slots, int rows, int T
     A.max_seq = c->dm.max_seq; A.rows = rows; A.T = T; A.slots = slots; A.base_len = base_len; A.x = c->x; A.bufs = c->r_bufs;
     A.err = c->seam_err_dev; A.ring_slots = 8; A.nchunks = nch; A.dbg = c->r_dbg;
     A.tok_in = tok_in; A.mel_emb = c->mel_emb; A.mel_pos = c->mel_pos; A.mel_pos_idx = c->st.mel_pos; A.vocab = c->dm.vocab;
-    static const int poll_all = getenv("GVC_ROWS_POLL_ALL") ? atoi(getenv("GVC_ROWS_POLL_ALL")) : 0;
-    A.poll_all = poll_all;
-    static const int rows_loader_depth = getenv("GVC_ROWS_LOADER_DEPTH") ? atoi(getenv("GVC_ROWS_LOADER_DEPTH")) : 2;
-    A.loader_depth = rows_loader_depth;
-    static const int rows_opt = getenv("GVC_ROWS_OPT") ? atoi(getenv("GVC_ROWS_OPT")) : 1;
-    A.opt = rows_opt;
-    static const int rows_copies = getenv("GVC_ROWS_COPIES") ? atoi(getenv("GVC_ROWS_COPIES")) : 8;
-    A.copies = rows_copies == 1 ? 1 : 8;
     // keys of a (row, head) over 2 / 4 workgroups: 8 rows from 80 / 160 cached positions (one 80-key pass per workgroup; 744 vs 766 us
     // per step at 48-112 keys, 815 vs 827 at 110-250), 16 rows from 128 / 288 (their chunk merge gathers 64 KB per chunk: 1068 vs 1104 us)
-    A.split1 = c->r_split1 > 0 ? c->r_split1 : (rows <= 8 ? 80 : 128);
-    A.split2 = c->r_split2 > 0 ? c->r_split2 : (rows <= 8 ? 160 : 288);
+    A.split1 = rows <= 8 ? 80 : 128;
+    A.split2 = rows <= 8 ? 160 : 288;
     void* kargs[] = {&A};
     GVC_CHECK_HIP(hipLaunchKernel(rows_kernel(c, rows <= 8 ? 8 : 16), dim3(persist_test_grid()), dim3(kPThreads), kargs, c->r_lds, s));
     GVC_LAUNCH_CHECK();
@@ -1067,12 +1041,92 @@ static int decode_group(gvc_gpt* c, const int32_t* slots, int B, int row0, const
 
 static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t s, const int32_t* base_len = nullptr, int key_chunks = 1);
 
+// double LayerNorm (ln_f, final_norm) of row (b * stride + off) of x -> latent[b]  (the head of a model wider than the GEMV kernels take)
+__global__ void k_head_ln(const float* x, int stride, int off, float* latent, int B, int d, const float* w1, const float* b1, const float* w2,
+                          const float* b2) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* in = x + ((size_t)b * stride + off) * d;
+    float* y = latent + (size_t)b * d;
+    const float inv_d = 1.0f / (float)d;
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* gw = pass == 0 ? w1 : w2;
+        const float* gb = pass == 0 ? b1 : b2;
+        float s = 0.f;
+        for (int k = lane * 4; k < d; k += 256) { const float4 v = *reinterpret_cast<const float4*>(in + k); s += (v.x + v.y) + (v.z + v.w); }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+        for (int k = lane * 4; k < d; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(in + k);
+            const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+        for (int k = lane * 4; k < d; k += 256) {
+            float4 v = *reinterpret_cast<const float4*>(in + k);
+            const float4 g = *reinterpret_cast<const float4*>(gw + k), c = *reinterpret_cast<const float4*>(gb + k);
+            v.x = (v.x - mean) * rstd * g.x + c.x; v.y = (v.y - mean) * rstd * g.y + c.y;
+            v.z = (v.z - mean) * rstd * g.z + c.z; v.w = (v.w - mean) * rstd * g.w + c.w;
+            *reinterpret_cast<float4*>(y + k) = v;
+        }
+        in = y;
+    }
+}
+
+// what EPI_LOGITS does behind the logits: the slots' caches grew by one position
+__global__ void k_head_advance(GptState st, const int32_t* slots, int B, int max_seq, int max_mel_pos, int32_t* step_ctr, int* err) {
+    const int t = threadIdx.x;
+    if (t < B) {
+        const int slot = slots[t];
+        if (st.seq_len[slot] < max_seq - 1) st.seq_len[slot] += 1;
+        else if (err) *err = 950;
+        if (st.mel_pos[slot] < max_mel_pos - 1) st.mel_pos[slot] += 1;
+        else if (err) *err = 951;
+    }
+    if (step_ctr && t == 0) *step_ctr += 1;
+}
+
+// gpt_inference.py:18,111-112 for the rows (b * x_stride + x_off) of x: latent = final_norm(ln_f(h)), logits = mel_head(latent).  Up to
+// d_model 1024 ONE GEMV launch with the two LayerNorms in its prologue (8 streams per launch); wider models: a LayerNorm launch + a GEMM
+static int launch_head(gvc_gpt* c, const int32_t* slots, int B, int row0, const float* x, int x_stride, int x_off, float* logits_out,
+                       float* latent_out, int advance, int32_t* step_ctr, hipStream_t s) {
+    const int d = c->dm.d_model;
+    int rc;
+    if (d <= 1024) {
+        for (int g = 0; g < B; g += 8) {
+            const int Bg = B - g < 8 ? B - g : 8;
+            GemvArgs A = base_args(c, slots + g, row0 + g);
+            A.x = const_cast<float*>(x) + (size_t)g * x_stride * d; A.x_stride = x_stride; A.x_off = x_off;
+            A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
+            A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
+            A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = advance;
+            A.step_ctr = g + 8 >= B ? step_ctr : nullptr;
+            if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;
+        }
+        return GVC_OK;
+    }
+    hipLaunchKernelGGL(k_head_ln, dim3(cdiv(B, 4)), dim3(256), 0, s, x, x_stride, x_off, latent_out, B, d, c->lnf_w, c->lnf_b, c->fn_w, c->fn_b);
+    GVC_LAUNCH_CHECK();
+    GemmArgs G;
+    memset(&G, 0, sizeof(G));
+    G.A = latent_out; G.lda = d; G.Wt = c->head_w; G.ldw = d; G.C = logits_out; G.ldc = c->dm.vocab; G.M = B; G.N = c->dm.vocab; G.K = d;
+    G.work = c->work; G.e.bias = c->head_b;
+    if ((rc = launch_gemm_cap(G, 1, c->work_cap, s))) return rc;
+    if (advance || step_ctr) {
+        hipLaunchKernelGGL(k_head_advance, dim3(1), dim3(128), 0, s, c->st, slots, advance ? B : 0, c->dm.max_seq, c->dm.max_mel_pos, step_ctr,
+                           c->seam_err_dev);
+        GVC_LAUNCH_CHECK();
+    }
+    return GVC_OK;
+}
+
 // Batched decode step on the MFMA path: the B new rows go through the skinny fragment-major GEMMs (weights streamed
 // once for up to 128 streams) instead of the 8-stream GEMV groups.  Same arithmetic as a prefill of one row per stream
 // appended at each slot's cached length.
 static bool rows_decode_ok(const gvc_gpt* c, int B) {
     if (c->r_ready >= 0 && rows_persist_ok(c, B, c->st.seq_len)) return true;       // served by the one-launch rows step (from 2 streams)
-    return c->rows_decode_min > 0 && B >= c->rows_decode_min && B <= 128 && c->skinny_prefill && c->wfm &&
+    const bool wide = c->dm.d_model > 1024;       // no GEMV path above 1024: every batch decodes as rows
+    return (wide || (c->rows_decode_min > 0 && B >= c->rows_decode_min)) && B <= 128 && c->skinny_prefill && c->wfm &&
            c->dm.d_model % 256 == 0 && (long long)4 * B * c->dm.d_model <= c->work_cap / 2 && B <= c->dm.max_rows;
 }
 
@@ -1087,16 +1141,7 @@ static int decode_rows(gvc_gpt* c, const int32_t* slots, int B, const int32_t* t
         GVC_LAUNCH_CHECK();
         if ((rc = run_rows(c, slots, B, 1, s, c->st.seq_len, key_chunks))) return rc;
     }
-    for (int g = 0; g < B; g += 8) {
-        const int Bg = B - g < 8 ? B - g : 8;
-        GemvArgs A = base_args(c, slots + g, g);
-        A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
-        A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
-        A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 1;
-        A.step_ctr = g + 8 >= B ? step_ctr : nullptr;
-        if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;
-    }
-    return GVC_OK;
+    return launch_head(c, slots, B, 0, c->x, 1, 0, logits_out, latent_out, 1, step_ctr, s);
 }
 
 static int check_ready(gvc_gpt* c) {
@@ -1195,7 +1240,7 @@ static int run_rows(gvc_gpt* c, const int32_t* slots, int B, int T, hipStream_t 
     // workgroup -- costs more than the two launches it saves): the row completion + LayerNorm runs
     // in the prologue of the QKV / c_fc GEMMs (5 launches per layer instead of 7); the residual stream ping-pongs between
     // c->x and c->xalt because only workgroup 0 of a launch writes the completed rows while the others still read them
-    if (skinny && rows <= c->fuse_ln_rows && c->fuse_ln) {
+    if (skinny && rows <= c->fuse_ln_rows && c->fuse_ln && d <= 1024) {
         float* X[2] = {c->x, c->xalt};
         int cur = 0;
         for (int l = 0; l < c->dm.n_layer; ++l) {
@@ -1351,15 +1396,7 @@ extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t 
         GVC_LAUNCH_CHECK();
         if ((rc = run_rows(c, slots, B, Tn, s, c->st.seq_len))) return rc;
     } else if ((rc = run_rows(c, slots, B, T, s))) return rc;
-    for (int g = 0; g < B; g += 8) {
-        const int Bg = B - g < 8 ? B - g : 8;
-        GemvArgs A = base_args(c, slots + g, 0);
-        A.x = c->x + (size_t)g * Tn * d; A.x_stride = Tn; A.x_off = Tn - 1;
-        A.Wt = c->head_w; A.Wt16 = c->head_h; A.bias = c->head_b; A.N = c->dm.vocab; A.K = d;
-        A.ln_w = c->lnf_w; A.ln_b = c->lnf_b; A.ln2_w = c->fn_w; A.ln2_b = c->fn_b;
-        A.out = logits_out + (size_t)g * c->dm.vocab; A.latent_out = latent_out + (size_t)g * d; A.advance = 0;
-        if ((rc = launch_gemv<PRO_LN2X, EPI_LOGITS>(c, A, Bg, s))) return rc;
-    }
+    if ((rc = launch_head(c, slots, B, 0, c->x, Tn, Tn - 1, logits_out, latent_out, 0, nullptr, s))) return rc;
     hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, T, 1);
     GVC_LAUNCH_CHECK();
     // park the next-step logits / latent per slot: gvc_gpt_generate continues every slot from here, whoever received them
@@ -1439,8 +1476,7 @@ struct GenPlan {
 
 static int step_unroll() {
     // the steps of a call run as graphs of kStepUnroll consecutive steps, the remainder one by one
-    static const int k = getenv("GVC_STEP_UNROLL") ? std::min(32, std::max(1, atoi(getenv("GVC_STEP_UNROLL")))) : 8;   // (<= 32: bits 24..29 of the graph key)
-    return k;
+    return 8;   // (<= 32: bits 24..29 of the graph key)
 }
 
 static int plan_generate(gvc_gpt* c, int B, int key_bound, int top_k, GenPlan* pl) {
@@ -1448,7 +1484,7 @@ static int plan_generate(gvc_gpt* c, int B, int key_bound, int top_k, GenPlan* p
     pl->fused = fused_ok(c, B, key_bound);
     // rows mode splits the keys of long contexts over 2 / 4 attention workgroups per (stream, head): two from GVC_ROWS_KEY_SPLIT
     // cached positions on (default 144; 0: never), four beyond 320
-    static const int key_split = getenv("GVC_ROWS_KEY_SPLIT") ? atoi(getenv("GVC_ROWS_KEY_SPLIT")) : 144;
+    constexpr int key_split = 144;
     if (persist_ok(c, B) && (rc = persist_prepare(c))) return rc;
     if (!persist_ok(c, B) && rows_persist_ok(c, B, c->st.seq_len) && (rc = rows_persist_prepare(c))) return rc;
     pl->key_chunks = (key_split > 0 && rows_decode_ok(c, B) && !persist_ok(c, B) && B <= 32)

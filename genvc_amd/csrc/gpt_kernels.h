@@ -966,9 +966,8 @@ __global__ __launch_bounds__(512) void k_attention_tile_short(const AttnArgs A) 
 // launch when the call is a prefill-shaped causal/direct one (T >= 16 rows per stream); false: the caller uses k_attention
 static inline bool launch_attention_tile(int head_dim, int n_head, const AttnArgs& T, int batch, int max_keys, hipStream_t s,
                                          bool kv_bf16, int* rc) {
-    static const int enabled = getenv("GVC_ATTN_TILE") ? atoi(getenv("GVC_ATTN_TILE")) : 1;
     // (few tiles -- one stream's segment prefix -- leave most CUs idle behind one latency chain: k_attention's row-per-workgroup grid wins)
-    if (!enabled || T.T < 16 || batch * ((T.T + 15) / 16) < 12 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return false;
+    if (T.T < 16 || batch * ((T.T + 15) / 16) < 12 || (head_dim != 64 && head_dim != 128 && head_dim != 256)) return false;
     const int nkp = (max_keys + 15) & ~15;
     if (nkp <= 128) {
         const size_t lds_short = ((size_t)16 * 132 + 16 + (size_t)(128 + 16) * (head_dim + 4)) * sizeof(float);

@@ -213,8 +213,8 @@ struct gvc_hubert {
     HbLn gn;
     std::vector<float*> conv_w;                   // layers 1.. : [Co][k*Ci]
     std::vector<float*> conv_wp;                  // ... and their FM16 copies for k_conv_lds (null: shape not eligible)
-    int conv_lds = 1;                             // GVC_HUBERT_CONV_LDS=0: convs 1.. always on the tiled GEMM
-    int conv_lds_rows = 256;                     // GVC_HUBERT_CONV_LDS_ROWS: layers with more output frames than this stay on the tiled GEMM
+    int conv_lds = 1;                             // feature-extractor convs 1.. on k_conv_lds (few output frames) or the tiled GEMM
+    int conv_lds_rows = 256;                     // layers with more output frames than this stay on the tiled GEMM
     HbLn feat_ln, enc_ln;
     HbLin proj, pos, fin;                         // pos.w: [E][kp*cg]
     std::vector<HbLayer> layers;
@@ -229,8 +229,8 @@ struct gvc_hubert {
     std::map<long long, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
     int use_graph = 1;
-    int skinny = 1;                               // GVC_HUBERT_SKINNY=0: always the tiled GEMM in the transformer
-    int strip = 1;                                // GVC_HUBERT_STRIP=0: more than 128 rows go to the tiled GEMM
+    int skinny = 1;                               // fragment-major transformer path (0 when the widths are not multiples of 128)
+    int strip = 1;                                // more than 128 rows: strip GEMM
     bool fm_ready = false;                        // FM16 copies match the bound weights
     float *xf = nullptr, *af = nullptr, *hf = nullptr;   // FM16 activations of the fragment-major path (all rows, 16-row tiles)
     std::vector<void*> allocs;
@@ -339,11 +339,7 @@ extern "C" int gvc_hubert_create(const gvc_hubert_dims* dims, gvc_hubert** out) 
     c->work_cap = 16ll << 20;
     if (!rc) rc = hb_alloc(c, &c->work, (size_t)c->work_cap);
     if (!rc && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = GVC_ERR_HIP;
-    if (getenv("GVC_HUBERT_GRAPH")) c->use_graph = atoi(getenv("GVC_HUBERT_GRAPH"));
-    if (getenv("GVC_HUBERT_SKINNY")) c->skinny = atoi(getenv("GVC_HUBERT_SKINNY"));
-    if (getenv("GVC_HUBERT_STRIP")) c->strip = atoi(getenv("GVC_HUBERT_STRIP"));
-    if (getenv("GVC_HUBERT_CONV_LDS")) c->conv_lds = atoi(getenv("GVC_HUBERT_CONV_LDS"));
-    if (getenv("GVC_HUBERT_CONV_LDS_ROWS")) c->conv_lds_rows = atoi(getenv("GVC_HUBERT_CONV_LDS_ROWS"));
+    if (getenv("GVC_GRAPHS")) c->use_graph = atoi(getenv("GVC_GRAPHS"));        // 0: eager launches (include/genvc_hip.h, environment switches)
     conv_lds_init_attributes();
     if (E % 128 != 0 || D.ffn_dim % 128 != 0) c->skinny = 0;
     if (rc) { gvc_hubert_destroy(c); return rc; }

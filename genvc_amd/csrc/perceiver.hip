@@ -90,10 +90,8 @@ struct gvc_perceiver {
     std::map<long long, hipGraphExec_t> graphs;    // (B, F) -> captured body of the forward (context-owned buffers only)
     std::map<long long, unsigned long long> graph_used;   // (B, F) -> tick of its last replay (eviction: least recently used)
     unsigned long long tick = 0;
-    hipStream_t cap_stream = nullptr, side_stream = nullptr;   // capture: the main chain, and the branch the later layers' context keys / values run on
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t cap_stream = nullptr;
     int use_graph = 1;               // GVC_PERCEIVER_GRAPH=0: eager launches
-    int fork = 0;                    // GVC_PERCEIVER_FORK=1: layers 1..'s context keys / values on a parallel branch of the graph (measured: slower)
 };
 
 extern "C" int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceiver** out) {
@@ -144,11 +142,7 @@ extern "C" int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceive
     GVC_CHECK_HIP(hipMalloc((void**)&c->work, (size_t)c->work_cap * sizeof(float)));
     GVC_CHECK_HIP(hipMalloc((void**)&c->tmp, 2 * fp * d * sizeof(float)));
     GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-    GVC_CHECK_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
-    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    GVC_CHECK_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    if (getenv("GVC_PERCEIVER_GRAPH")) c->use_graph = atoi(getenv("GVC_PERCEIVER_GRAPH"));
-    if (getenv("GVC_PERCEIVER_FORK")) c->fork = atoi(getenv("GVC_PERCEIVER_FORK"));
+    if (getenv("GVC_GRAPHS")) c->use_graph = atoi(getenv("GVC_GRAPHS"));        // 0: eager launches (include/genvc_hip.h, environment switches)
     gemm_init_attributes();
     *out = c;
     return GVC_OK;
@@ -158,9 +152,6 @@ extern "C" int gvc_perceiver_destroy(gvc_perceiver* c) {
     if (!c) return GVC_OK;
     for (auto& kvp : c->graphs) (void)hipGraphExecDestroy(kvp.second);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (void* p : {(void*)c->wbase, (void*)c->C, (void*)c->X, (void*)c->kv, (void*)c->o, (void*)c->g, (void*)c->xp, (void*)c->work,
                     (void*)c->tmp})
         if (p) hipFree(p);
@@ -265,7 +256,7 @@ static int perc_stage_in(gvc_perceiver* c, const float* x, int B, int F, hipStre
 }
 
 // `side`: a second stream of the same capture (null: everything in order on s)
-static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s, hipStream_t side) {
+static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
     const int d = c->dm.dim, in = c->inner, NL = c->dm.num_latents, R = NL + F, depth = c->dm.depth, fp = c->ffi_p;
     const int ldkv = depth * 3 * in;                  // floats per row of KV: [depth][q | k | v]
     int rc;
@@ -292,14 +283,8 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s, hipStream_
         G.M = F; G.N = 2 * in; G.K = d; G.work = nullptr;             // (no split-K: the branch must not share the work buffer)
         return launch_gemm_cap(G, B * nl, 0, st);
     };
-    const bool fork = side != nullptr && depth > 1 && c->fork;
-    if (fork) {
-        GVC_CHECK_HIP(hipEventRecord(c->ev_fork, s));
-        GVC_CHECK_HIP(hipStreamWaitEvent(side, c->ev_fork, 0));
-        if ((rc = ctx_kv(1, depth - 1, side))) return rc;
-        GVC_CHECK_HIP(hipEventRecord(c->ev_join, side));
-        if ((rc = ctx_kv(0, 1, s))) return rc;
-    } else if ((rc = ctx_kv(0, depth, s))) return rc;
+    // (the later layers' context keys / values on a parallel graph branch: measured slower, removed -- profiles/r06_removed_experiments.patch)
+    if ((rc = ctx_kv(0, depth, s))) return rc;
     // X = latents, fragment-major, one copy per batch element.  One batch element (the usual call: one reference chunk): no copy --
     // layer 0 reads the parameter itself (A operand of its q | k | v GEMM, residual of its to_out) and writes X
     if (B > 1) {
@@ -319,7 +304,6 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s, hipStream_
             if ((rc = launch_gemm_skinny(G, 1, c->work_cap, s))) return rc;
         }
         // cross-attention of the 32 latent queries over latents + context, output fragment-major [B * 32][inner]
-        if (fork && l == 1) GVC_CHECK_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
         {
             const float* qb = c->kv + (size_t)l * 3 * in;
             hipLaunchKernelGGL((k_attn64_mfma<false, 16>), dim3(NL / 16, c->dm.heads, B), dim3(1024), 0, s, qb, qb + in, qb + 2 * in, (long long)ldkv,
@@ -357,7 +341,7 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
     if ((rc = perc_prepare(c, s))) return rc;
     if ((rc = perc_stage_in(c, x, B, F, s))) return rc;
     if (!c->use_graph) {
-        if ((rc = perc_launch(c, B, F, s, nullptr))) return rc;
+        if ((rc = perc_launch(c, B, F, s))) return rc;
     } else {
         // the body works on context-owned buffers only: one graph per (B, F), whatever the caller's pointers
         const long long key = (long long)B * 100000 + F;
@@ -376,7 +360,7 @@ extern "C" int gvc_perceiver_forward(gvc_perceiver* c, const float* x, int32_t B
             }
             hipGraph_t graph = nullptr;
             GVC_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-            rc = perc_launch(c, B, F, c->cap_stream, c->side_stream);
+            rc = perc_launch(c, B, F, c->cap_stream);
             hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
             if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             GVC_CHECK_HIP(e);

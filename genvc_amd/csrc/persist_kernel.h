@@ -46,6 +46,7 @@ constexpr int kPMaxChunks = 8;      // key chunks per head
 constexpr int kPU = 4;              // keys per lane group held in registers per pass
 constexpr int kPUF = 10;            // ... in the fused attention + projection phase (short contexts: kPUF * kPCW keys)
 constexpr unsigned kPSpinLimit = 400000;
+constexpr int kPStampLayer = 2;     // GVC_PERSIST_STAMPS: the layer whose phases every workgroup stamps
 // LDS control words
 constexpr int kCtlFilled = 0, kCtlDone = 1, kCtlArrive = 1 + kPCW, kCtlAbort = 2 + kPCW, kCtlXcd = 3 + kPCW, kCtlWords = 16;
 
@@ -75,11 +76,6 @@ struct PersistArgs {
     int ring_slots;                 // power of two
     int hvec_floats, ascr_floats;
     unsigned long long* dbg;        // nullable: wall-clock stamps
-    int loader_depth;               // LDS-DMA fills in flight per loader wave (1..3; default 1)
-    int nosent;                     // GVC_PERSIST_NOSENT: bit 0 / bit 1: phase D's / phase A's gather polls every plane in every pass (no sentinel round trip)
-    int dbg_layer;                  // GVC_PERSIST_STAMPS: the layer whose phases every workgroup stamps (GVC_PERSIST_STAMP_LAYER, default 2)
-    int ln_one_pass;                // experiment: LayerNorm statistics in one pass (GVC_PERSIST_LN_ONE_PASS=1; default 0 = the reference's two-pass form)
-    int poll_b, poll_h;             // back-off (s_sleep argument class 0 / 1 / 3) between polls of the q|k|v gather and of the XCD-local h gather
 };
 
 // granules of the hand-off buffers (host: allocation size)
@@ -178,7 +174,7 @@ __device__ __forceinline__ void publish_local(__amdgpu_buffer_rsrc_t rs, int ind
 // gd (diagnostics, GVC_PERSIST_STAMPS): [0] entry, [1] sentinel seen, [2] done (wall clock), [3] sentinel polls, [4] sweep passes
 template <int NJ, int NP>
 __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int base, int n, unsigned tag, float* dst, int code, int sleep = 3,
-                                       unsigned long long* gd = nullptr, bool no_sentinel = false) {
+                                       unsigned long long* gd = nullptr) {
     if (c.dead || c.wave * 128 >= n) return;         // a wave is all in or all out
     const int t0 = 2 * (c.wave * 64 + c.lane);
     const int voff = (base + t0) * 8;
@@ -188,7 +184,7 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
     constexpr bool kSentinel = NJ > 1 || NP > 2;      // one load per lane on <= 2 planes: every poll pass reads everything (one round trip less)
     unsigned npoll = 0, npass = 0;
     if (gd) gd[0] = wall_clock64();
-    while (kSentinel && !no_sentinel) {
+    while (kSentinel) {
         v[0][NP - 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (NP - 1) * n * 8, 16);
         ++npoll;
         if (__all(v[0][NP - 1].y == tag && v[0][NP - 1].w == tag)) break;
@@ -203,7 +199,7 @@ __device__ __forceinline__ void gather(PCtx& c, __amdgpu_buffer_rsrc_t rs, int b
             if (j == 0 || c.wave * 128 + j * JT < n) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    if (!(kSentinel && !no_sentinel && j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
+                    if (!(kSentinel && j == 0 && p == NP - 1)) v[j][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (j * JT + p * n) * 8, 16);
             }
         }
 #pragma unroll
@@ -260,33 +256,20 @@ __device__ __forceinline__ float row_partial(const char* ring, unsigned rmask, u
 }
 
 template <int ND>
-__device__ __forceinline__ void layer_norm_regs(float4 (&v)[ND], const float4 (&g)[ND], const float4 (&b)[ND], bool one_pass = false) {
+__device__ __forceinline__ void layer_norm_regs(float4 (&v)[ND], const float4 (&g)[ND], const float4 (&b)[ND]) {
     const float inv_d = 1.0f / (float)(256 * ND);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < ND; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    float mean, rstd;
-    if (one_pass) {
-        // experiment: sum and sum of squares reduced side by side -- the two lane trees overlap instead of
-        // running one after the other; var = E[x^2] - mean^2 (another rounding than the reference's two-pass form)
-        float q = 0.f;
+    // (two passes, the reference's form; the one-pass E[x^2] - mean^2 variant was measured and dropped: profiles/r06_removed_experiments.patch)
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < ND; ++i) q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-        const float ts = wave_sum(s), tq = wave_sum(q);
-        mean = ts * inv_d;
-        rstd = 1.0f / sqrtf(fmaxf(tq * inv_d - mean * mean, 0.f) + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < ND; ++i) { v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean; }
-    } else {
-        mean = wave_sum(s) * inv_d;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-        }
-        rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
+    for (int i = 0; i < ND; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + 1e-5f);
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
@@ -428,17 +411,19 @@ __device__ __forceinline__ void persist_loader(const PersistArgs& A, PCtx& c, ch
                 for (int i = 0; i < 16; ++i)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(i >> 1) * kib_stride + (i & 1) * 1024),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-                if (A.loader_depth >= 3) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (fseq) lds_st(c.ctl + kCtlFilled, fseq - 1); }
-                else if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
-                else { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq); }
-            } else if (n == 16) {    // thinned: at most this fill and the one before it in flight
+                // ONE fill in flight: enough to keep up (11 KB/us per CU) and it leaves the memory queue to the consumers' polls (two / three in
+                // flight: +0.5 % / +4 %, profiles/r04_microbench_notes.md)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_st(c.ctl + kCtlFilled, fseq + 1);
+            } else if (n == 16) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)i * kib_stride),
                                                      (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-                if (A.loader_depth >= 3) { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); if (fseq) lds_st(c.ctl + kCtlFilled, fseq - 1); }
-                else if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
-                else { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq); }
+                // ONE fill in flight: enough to keep up (11 KB/us per CU) and it leaves the memory queue to the consumers' polls (two / three in
+                // flight: +0.5 % / +4 %, profiles/r04_microbench_notes.md)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_st(c.ctl + kCtlFilled, fseq + 1);
             } else {
 #pragma unroll 1
                 for (unsigned i = 0; i < n; ++i)
@@ -538,7 +523,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
         const int base2 = 4 * 5 * (A.n_layer + 2);
         auto stamp_at = [&](int l, int p, int k) {
             if (stamp0 && wg == 0) A.dbg[(l * 5 + p) * 4 + k] = wall_clock64();
-            if (stamp0 && l == A.dbg_layer && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
+            if (stamp0 && l == kPStampLayer && k < 2) A.dbg[base2 + (wg * 5 + p) * 2 + k] = wall_clock64();
         };
         unsigned fs = 0;                                 // first fill of the current weight segment
         constexpr unsigned nfA = (((3 * ND * D * 4) >> WB) + kPSlot - 1) / kPSlot, nfC = (((ND * D * 4) >> WB) + kPSlot - 1) / kPSlot,
@@ -567,13 +552,13 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int nmy = wave < RA ? (RA - wave + kPCW - 1) / kPCW : 0;
                 const int row_g = wg * RA + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.qkv_b[row_g] : 0.f;
-                if (l > 0) gather<NJX, NPX>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l, 3, nullptr, (A.nosent & 2) != 0);
+                if (l > 0) gather<NJX, NPX>(c, grs, iX1, D, tag_of(l - 1, 4), xvec, 100 + l, 3, nullptr);
                 cbar(c);
                 stamp_at(l, 0, 0);
                 float val = 0.f;
                 if (nmy > 0) {
                     vec_from_lds<ND>(xvec, lane, xv);
-                    layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
+                    layer_norm_regs<ND>(xv, g, b);
                     stamp_at(l, 0, 2);
                     wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
@@ -783,7 +768,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                     while (true) {
                         v = __builtin_amdgcn_raw_buffer_load_b128(grs, off, 0, 16);
                         if (__all(v.y == tg && v.w == tg)) break;
-                        if (spin_fail(c, spins, 200 + l, A.poll_b)) break;
+                        if (spin_fail(c, spins, 200 + l, 3)) break;
                     }
                     *reinterpret_cast<float2*>(ascr + t) = make_float2(__uint_as_float(v.x), __uint_as_float(v.z));
                 }
@@ -903,10 +888,10 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int row_g = dwg * RD + wave + kPCW * lane;
                 const float bias = lane < nmy ? Ly.fc_b[row_g] : 0.f;
                 // (diagnostics: wave 0's gather of layer 2 in every workgroup -> [base3 + wg * 8 + ..], and the workgroup's XCD / rank)
-                unsigned long long* gdD = (A.dbg && l == A.dbg_layer && wave == 0) ? A.dbg + base2 + 2 * 5 * kPG + wg * 8 : nullptr;
+                unsigned long long* gdD = (A.dbg && l == kPStampLayer && wave == 0) ? A.dbg + base2 + 2 * 5 * kPG + wg * 8 : nullptr;
                 if (gdD && lane == 0) gdD[5] = XL ? (unsigned long long)(((xx & 7) << 8) | jj) : 0xffffull;
                 if (!fused) gather<NJX, KSC>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
-                else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l, 3, gdD, (A.nosent & 1) != 0);
+                else if (H == 4) gather<NJX, 4>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l, 3, gdD);
                 else if (H == 2) gather<NJX, 2>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 else gather<NJX, 1>(c, grs, iX0, D, tag_of(l, 2), xvec, 400 + l);
                 cbar(c);
@@ -914,7 +899,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 float val = 0.f;
                 if (nmy > 0) {
                     vec_from_lds<ND>(xvec, lane, xv);
-                    layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
+                    layer_norm_regs<ND>(xv, g, b);
                     wait_fill(c, fs + ((unsigned)((wave + kPCW * (nmy - 1)) * D * 4 + D * 4 - 1) >> FSH));
                     float part[UPW];
 #pragma unroll
@@ -940,7 +925,7 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
                 const int x8 = xx & 7;
                 const int orow = 32 * jj + 4 * wave + lane;                  // (lanes 0..3: the wave's four rows)
                 const float bias = x8 == 0 && lane < 4 ? Ly.p2_b[orow] : 0.f;
-                gather<1, 1>(c, grs, iH + 512 * x8, 512, tag_of(l, 3), hvec, 500 + l, A.poll_h);       // one 16-byte load per lane of waves 0..3
+                gather<1, 1>(c, grs, iH + 512 * x8, 512, tag_of(l, 3), hvec, 500 + l, 3);       // one 16-byte load per lane of waves 0..3
                 cbar(c);
                 stamp_at(l, 4, 0);
                 float4 hv[2];
@@ -1004,8 +989,8 @@ __global__ __launch_bounds__(kPThreads) void k_decode_persist(const PersistArgs 
             cbar(c);
             stamp_at(L, 0, 0);
             vec_from_lds<ND>(xvec, lane, xv);
-            layer_norm_regs<ND>(xv, g, b, A.ln_one_pass != 0);
-            layer_norm_regs<ND>(xv, g2, b2, A.ln_one_pass != 0);
+            layer_norm_regs<ND>(xv, g, b);
+            layer_norm_regs<ND>(xv, g2, b2);
             if (wg == 0 && wave == 0) {
 #pragma unroll
                 for (int i = 0; i < ND; ++i) *reinterpret_cast<float4*>(A.latent_out + i * 256 + lane * 4) = xv[i];

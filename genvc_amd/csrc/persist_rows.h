@@ -77,10 +77,6 @@ struct RowsArgs {
     int* err;
     int ring_slots, nchunks;        // nchunks: upper bound of the key split (the kernel picks 1 / 2 / 4 from the longest context it finds)
     int split1, split2;             // cached positions from which the keys of a (row, head) take 2 / 4 workgroups
-    int poll_all;                   // gathers of up to this many 16-byte pieces per lane re-request everything in every poll pass
-    int loader_depth;               // LDS-DMA fills in flight per loader wave (1 or 2)
-    int copies;                     // bf16-activation mode (persist_rows_b16.h): per-XCD copies of the gathered hand-off buffers (1 or 8)
-    int opt;                        // A/B switches (GVC_ROWS_OPT, default 1): bit 0: every wave of phase B gathers q itself (else wave 0 -> LDS -> barrier)
     unsigned long long* dbg;
 };
 
@@ -325,12 +321,10 @@ __device__ __forceinline__ void rows_loader(const RowsArgs& A, PCtx& c, char* ri
             for (int i = 0; i < NP; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                                  (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 2);
-            if (A.loader_depth == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_st(c.ctl + kCtlFilled, fseq + 1); }
-            else {
-                if (WB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                lds_st(c.ctl + kCtlFilled, fseq);
-            }
+            // two fills in flight (this one and the one before it)
+            if (WB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            lds_st(c.ctl + kCtlFilled, fseq);
             ++fseq;
         }
     }
@@ -632,21 +626,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             kn[0] = vn[0] = kn[1] = vn[1] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int j0 = (wave + kPCW - 1) & (kPCW - 1);
             const int qoff = pc + (kRoffQKV + n * 3 * D + h * HD) * 4 + lane * 16;
-            if (!(A.opt & 1)) {                                  // round-4 form: wave 0 stages q in LDS, one more barrier
-                if (wave == 0 && active) {
-                    pu32x4 qv[1];
-                    rgather<1>(c, brs, qoff, 0, qv, 200 + l);
-                    *reinterpret_cast<float4*>(ascr + lane * 4) = as_f4(qv[0]);
-                }
-                if (last && j0 <= t) {
-                    has_new[0] = true;
-                    pu32x4 kv[2];
-                    rgather<2>(c, brs, pc + (kRoffQKV + (r0 + j0) * 3 * D + D + h * HD) * 4 + lane * 16, D * 4, kv, 210 + l);
-                    kn[0] = as_f4(kv[0]); vn[0] = as_f4(kv[1]);
-                }
-                cbar(c);
-                q4 = *reinterpret_cast<const float4*>(ascr + lane * 4);
-            } else if (last && j0 <= t && r0 + j0 == n) {        // (wave-uniform)
+            if (last && j0 <= t && r0 + j0 == n) {               // (wave-uniform)
                 has_new[0] = true;
                 pu32x4 qkv[3];
                 rgather<3>(c, brs, qoff, D * 4, qkv, 200 + l, true);
@@ -757,7 +737,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->proj_b + wg * 4);
             if (nch == 1) {                                  // one chunk: its partial IS the head output (already normalised)
                 pu32x4 raw[NSX];
-                rgather<NSX>(c, brs, pc + kRoffOP * 4 + s0 * 1024 + lane * 16, 1024, raw, 300 + l, NSX <= A.poll_all);
+                rgather<NSX>(c, brs, pc + kRoffOP * 4 + s0 * 1024 + lane * 16, 1024, raw, 300 + l);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) ov[i] = as_f4(raw[i]);
             } else {
@@ -881,7 +861,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             if (lane < 32) *reinterpret_cast<float4*>(gbs + (wave * 64 + lane) * 4) = *reinterpret_cast<const float4*>(Lp->ln2_w + (s0 * KK + lane) * 4);
             {
                 pu32x4 raw[NSX];
-                rgather<NSX>(c, brs, pc + kRoffX0 * 4 + s0 * 1024 + lane * 16, 1024, raw, 400 + l, NSX <= A.poll_all);
+                rgather<NSX>(c, brs, pc + kRoffX0 * 4 + s0 * 1024 + lane * 16, 1024, raw, 400 + l);
 #pragma unroll
                 for (int i = 0; i < NSX; ++i) xv[i] = as_f4(raw[i]);
             }
@@ -995,7 +975,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist(const RowsArgs A) {
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + cb * 8 + (wave & 1) * 4);
             pf32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             pu32x4 raw[NSE];
-            rgather<NSE>(c, brs, pc + kRoffHH * 4 + (kh * kPCW * NSE + sl) * 1024 + lane * 16, 1024, raw, 500 + l, NSE <= A.poll_all);
+            rgather<NSE>(c, brs, pc + kRoffHH * 4 + (kh * kPCW * NSE + sl) * 1024 + lane * 16, 1024, raw, 500 + l);
             stamp_at(l, 4, 0);
             {
                 // group ge lies in fills fs + 2 ge, fs + 2 ge + 1 (32 KiB of fp32); the wave's NSE steps sit inside one fill

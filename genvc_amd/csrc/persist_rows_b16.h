@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist_b16(const RowsArgs A
     }
     const __amdgpu_buffer_rsrc_t brs = make_rsrc(A.bufs, (unsigned)rows_b16_buf_bytes());
     // the copy of the replicated hand-off buffers this workgroup reads: the one of its XCD
-    const int ncopy = A.copies;
+    constexpr int ncopy = kBCopies;
     int rep;
     {
         unsigned xcc;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist_b16(const RowsArgs A
                     xr[i] = (pu32x4){pa.x, pa.y, pb.x, pb.y};
                 }
             } else {
-                rgather<NSX>(c, brs, po + rep + kBoffX1 + s0 * 1024 + lane * 16, 1024, xr, 100 + l, NSX <= 2 || NSX <= A.poll_all);
+                rgather<NSX>(c, brs, po + rep + kBoffX1 + s0 * 1024 + lane * 16, 1024, xr, 100 + l, NSX <= 2);
             }
             stamp_at(l, 0, 0);
             wait_fill(c, fs + 2);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist_b16(const RowsArgs A
             pu32x4 ovh[NSX];
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->proj_b + wg * 4);
             if (nch == 1) {
-                rgather<NSX>(c, brs, pc + rep + kBoffOPH + s0 * 1024 + lane * 16, 1024, ovh, 300 + l, NSX <= 2 || NSX <= A.poll_all);
+                rgather<NSX>(c, brs, pc + rep + kBoffOPH + s0 * 1024 + lane * 16, 1024, ovh, 300 + l, NSX <= 2);
             } else {
                 // several chunks: fp32 partials (two pieces per step: the octet's two quads) merged in chunk order, then rounded
                 constexpr int NP = 2 * NSX;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist_b16(const RowsArgs A
             pu32x4 xr[NSX];
             const float4 Spre = *reinterpret_cast<const float4*>(Lp->lnS_d + wg * 16 + (wave & 3) * 4);
             const float4 Cpre = *reinterpret_cast<const float4*>(Lp->lnC_d + wg * 16 + (wave & 3) * 4);
-            rgather<NSX>(c, brs, pc + rep + kBoffX0 + s0 * 1024 + lane * 16, 1024, xr, 400 + l, NSX <= 2 || NSX <= A.poll_all);
+            rgather<NSX>(c, brs, pc + rep + kBoffX0 + s0 * 1024 + lane * 16, 1024, xr, 400 + l, NSX <= 2);
             stamp_at(l, 3, 0);
             wait_fill(c, fs + 3);
             stamp_at(l, 3, 3);
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kPThreads) void k_rows_persist_b16(const RowsArgs A
             const float4 bpre = *reinterpret_cast<const float4*>(Lp->p2_b + wg * 4);
             pf32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             pu32x4 hv[NSE];
-            rgather<NSE>(c, brs, pc + rep + kBoffHH + sl * 1024 + lane * 16, 1024, hv, 500 + l, NSE <= A.poll_all);
+            rgather<NSE>(c, brs, pc + rep + kBoffHH + sl * 1024 + lane * 16, 1024, hv, 500 + l);
             stamp_at(l, 4, 0);
             {
                 wait_fill(c, fs + (wave >> 1));

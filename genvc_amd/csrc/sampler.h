@@ -31,8 +31,7 @@ int launch_sample(const SampleCall& sc, hipStream_t s);
 // greedy: the call has top_k == 1 (sample_greedy_ok): the argmax-only kernel
 int launch_sample_indirect(const SampleCall* sc_dev, int B, bool greedy, hipStream_t s);
 static inline bool sample_greedy_ok(int top_k, int d) {
-    static const bool on = !getenv("GVC_SAMPLE_GREEDY") || atoi(getenv("GVC_SAMPLE_GREEDY")) != 0;      // 0: always the general kernel
-    return on && top_k == 1 && d % 4 == 0;
+    return top_k == 1 && d % 4 == 0;
 }
 
 }  // namespace gvc

@@ -36,6 +36,8 @@ class GptEngine:
                           dims["max_mel_pos"], dims["max_text_pos"], dims["number_text_tokens"], max_seq,
                           max_slots, max_rows, {"fp32": 0, "bf16": 1, "bf16_kv": 2, "bf16_act": 3}[weight_dtype])
         self._h = C.c_void_p()
+        self._pending_side = None     # end-of-work event of another stream of this process (watch_stream)
+        self.side_joins = 0
         check(lib().gvc_gpt_create(C.byref(cd), C.byref(self._h)), "gvc_gpt_create")
 
     def close(self):
@@ -71,9 +73,26 @@ class GptEngine:
                                               ptr(out), stream()), "prefix_embeddings")
         return out
 
+    def watch_stream(self, event):
+        """Residency before issue: the one-launch steps need all 256 workgroups co-resident, so work of this process that is still in
+        flight on ANOTHER stream (the conditioning side stream of model_init._CondFuture: mel + Perceiver, ~25 short launches) must not
+        overlap them -- a missing workgroup costs a ~0.2 s bounded spin and a fallback (include/genvc_hip.h: gvc_gpt_health).  The owner of
+        such a stream registers the event that marks the end of its work here; the next prefill / decode_step / generate / latents call
+        makes the caller's stream wait for it first (`side_joins` counts the calls that really had to wait)."""
+        self._pending_side = event
+
+    def _join_side(self):
+        ev = self._pending_side
+        if ev is not None:
+            self._pending_side = None
+            if not ev.query():
+                torch.cuda.current_stream().wait_event(ev)
+                self.side_joins += 1
+
     def prefill(self, slots, prefix_emb, want_outputs=True, n_cached=0):
         """n_cached > 0: the first n_cached rows of the prefix (the conditioning latents) are already in the slots' KV
         cache from an earlier prefill with the same leading rows -- only the rest is computed (bit-identical results)"""
+        self._join_side()
         B, P, _ = prefix_emb.shape
         logits = latent = None
         if want_outputs:
@@ -84,6 +103,7 @@ class GptEngine:
         return logits, latent
 
     def decode_step(self, slots, tok, logits=None, latent=None):
+        self._join_side()
         B = slots.shape[0]
         if logits is None:
             logits = torch.empty(B, self.V, device=slots.device, dtype=torch.float32)
@@ -96,6 +116,7 @@ class GptEngine:
         check(lib().gvc_gpt_reset_slots(self._h, ptr(_i32(slots)), slots.shape[0], stream()), "reset_slots")
 
     def latents(self, slots, prefix_emb, gen_codes):
+        self._join_side()
         B, P, _ = prefix_emb.shape
         n = gen_codes.shape[1]
         out = torch.empty(B, n, self.d, device=prefix_emb.device, dtype=torch.float32)
@@ -115,6 +136,7 @@ class GptEngine:
         """tokens_out [B, >= i0+n_steps] int32 and latents_out [B, >= i0+n_steps, d] may be column slices of larger
         buffers (row strides are passed on); step i of this call lands in column i0 + i.  max_keys: cached positions of the
         longest stream after the call (0: unknown, the width of `ids` is taken)."""
+        self._join_side()
         B = slots.shape[0]
         assert tokens_out.is_cuda and tokens_out.dtype == torch.int32 and tokens_out.stride(1) == 1
         lat_stride = 0

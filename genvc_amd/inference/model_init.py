@@ -160,6 +160,12 @@ class _CondFuture:
         with torch.cuda.stream(side):
             self.cond = model.get_gpt_cond_latents(audio, sr, length, chunk_length)
         self.side = side
+        # residency before issue: a GPT call on another stream (a one-launch step needs every CU) waits for this chain first
+        done = torch.cuda.Event()
+        done.record(side)
+        eng = getattr(model.gpt, "engine", None)
+        if eng is not None:
+            eng.watch_stream(done)
 
     def result(self):
         main = torch.cuda.current_stream(self.cond.device)

@@ -19,6 +19,23 @@
  *     allocated in *_create;
  *   - a context is bound to the device that was current at *_create and must not be used
  *     from two host threads at once; contexts are independent of each other.
+ *
+ * Environment switches read by the library (ten; everything else that used to be a run-time knob is a constant now, and the
+ * experiments that lost are gone from the kernels: profiles/r06_removed_experiments.patch).  All default to the shipped configuration.
+ *   GVC_PERSIST=0            never use the one-launch steps (one stream and 2..16 rows then take the launch-per-phase paths)
+ *   GVC_PERSIST_ROWS=0       2..16 rows keep the launch-per-phase rows path (the one-stream one-launch step stays on)
+ *   GVC_PERSIST_XCD=0        one-stream step: device-wide hand-off of the MLP's hidden units instead of the XCD-local layout
+ *                            (for partition modes in which a 256-workgroup grid is not dealt 8 x 32 over the XCDs; the topology
+ *                            probe switches it off by itself when it sees such a deal)
+ *   GVC_PERSIST_TEST_GRID=n  test hook: launch the one-launch steps with n < 256 workgroups (every hand-off then times out)
+ *   GVC_PERSIST_STAMPS=1     in-kernel wall-clock stamps of the one-launch steps (scripts/stamps_persist.py, scripts/stamps_rows.py)
+ *   GVC_DEBUG_STAMPS=1       in-kernel stamps of the launch-per-phase decode kernels (scripts/stamps.py)
+ *   GVC_ROWS_DECODE_MIN=n    smallest batch that decodes on the MFMA rows path when the one-launch rows step does not serve it
+ *                            (default 5; 0: never -- the 8-stream GEMV groups; tests use it to reach both paths)
+ *   GVC_GRAPHS=0             ContentVec and Perceiver: eager launches instead of one hipGraph per shape
+ *   GVC_VOCODER_GRAPH=0|2    HiFi-GAN: eager launches / only the conv chain as a graph (default 1: the whole call)
+ *   GVC_VOCODER_SMALL_CONV=0|2  HiFi-GAN: every conv on the tiled GEMM / only the ResBlocks on k_conv_lds (the paths other shapes take)
+ * Outside the library: GENVC_HIP_LIB (genvc_amd/_lib.py: another build of the library, for A/B runs), GVC_BENCH_* (bench.py dry runs).
  */
 #ifndef GENVC_HIP_H
 #define GENVC_HIP_H

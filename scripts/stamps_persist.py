@@ -36,7 +36,7 @@ ws = np.diff(np.concatenate([d[:-1, -1:], d[1:, :]], axis=1), axis=1)[:, 0::2]  
 print("workgroup 0, waits per layer (A B C D E):")
 for i in range(0, ws.shape[0], 4):
     print("   " + "   ".join(f"l{i+2+j:2d}: " + " ".join(f"{v:4.1f}" for v in ws[i + j]) for j in range(min(4, ws.shape[0] - i))))
-LS = int(os.environ.get("GVC_PERSIST_STAMP_LAYER", "2"))
+LS = 2          # the layer every workgroup stamps (csrc/persist_kernel.h: kPStampLayer)
 ex = np.array([[W(l, 0, 2) - W(l, 0, 0), W(l, 0, 3) - W(l, 0, 2), W(l, 0, 1) - W(l, 0, 3),
                 W(l, 1, 2) - W(l, 1, 0), W(l, 1, 3) - W(l, 1, 2), W(l, 1, 1) - W(l, 1, 3)] for l in range(2, nl)]).mean(axis=0)
 print("A: LN %.2f rows %.2f publish %.2f | B: scores+fold %.2f combine barrier %.2f merge+publish %.2f" % tuple(ex))

@@ -540,13 +540,15 @@ def test_config4_batched_prefill_agrees_with_single_segments():
         np.testing.assert_allclose(lats_1[0].numpy(), lats_b[b].numpy(), atol=1e-4)
 
 
-@pytest.mark.parametrize("d,H,L", [(1024, 16, 4), (512, 4, 4), (768, 12, 2), (768, 3, 2), (512, 8, 2), (512, 4, 3)],
-                         ids=["d1024_h16_hd64", "d512_h4_hd128", "d768_h12_hd64", "d768_h3_hd256", "d512_h8_hd64", "odd_layer_count"])
+@pytest.mark.parametrize("d,H,L", [(1024, 16, 4), (512, 4, 4), (768, 12, 2), (768, 3, 2), (512, 8, 2), (512, 4, 3), (1280, 20, 2), (2048, 16, 2), (1536, 6, 2)],
+                         ids=["d1024_h16_hd64", "d512_h4_hd128", "d768_h12_hd64", "d768_h3_hd256", "d512_h8_hd64", "odd_layer_count",
+                              "d1280_h20_hd64", "d2048_h16_hd128", "d1536_h6_hd256"])
 @pytest.mark.parametrize("persist", ["1", "0"], ids=["one_launch_step", "launch_per_phase"])
 def test_other_model_dims_vs_oracle(d, H, L, persist, monkeypatch):
     """the real checkpoints' dims live in their config (inference/model_init.py:11-12; configs/genVC_configs.py:132 defaults to 16
     heads): every multiple of 256 up to 1024 with head_dim 64 / 128 / 256 -- prefill, teacher-forced decode steps of one stream
-    (both decode paths) and of three streams (8-stream GEMV groups), and the latent re-pass, against the oracle"""
+    (both decode paths) and of three streams (8-stream GEMV groups), and the latent re-pass, against the oracle.  Round 6: widths above
+    1024 (1280 = 20 x 64, 2048 = 16 x 128, 1536 = 6 x 256), which run prefill and decode alike as rows on the GEMM paths"""
     from oracle import genvc_oracle as O
     monkeypatch.setenv("GVC_PERSIST", persist)
     margs = dict(gcfg.TINY_MODEL_ARGS, gpt_layers=L, gpt_n_model_channels=d, gpt_n_heads=H)

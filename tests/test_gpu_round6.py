@@ -164,7 +164,8 @@ def test_rows_step_bf16_activations_vs_oracle(L, B, Tc, n, H):
       * step 0 (the prefill's row: GEMM path, fp32 activations) agrees to 2e-3 like mode 2;
       * the latents of the rows steps deviate from the oracle by no more than the ORACLE ITSELF deviates when its input moves by 2e-7
         relative (median and 99.9 % quantile within 2x of that yardstick): the kernel is inside the oracle's reproducibility ball;
-      * >= 85 % of the greedy ids equal the oracle's, and a first divergence only where the oracle's own top-1 / top-2 gap is < 1e-2."""
+      * >= 85 % of the greedy ids equal the oracle's, and a first divergence only where the oracle's own top-1 / top-2 gap is < 2e-2 (the latents'
+        reproducibility noise, ~2e-3 median / 2e-2 max, is ~1e-2 in the logits)."""
     toks, lats, ref_t, ref_l, pert_l, margins = _act_bf16_case(L, B, Tc, n, H)
     np.testing.assert_allclose(lats[:, 0].numpy(), ref_l[:, 0].numpy(), atol=2e-3)
     agree = toks == ref_t
@@ -179,7 +180,7 @@ def test_rows_step_bf16_activations_vs_oracle(L, B, Tc, n, H):
     for b in range(B):
         bad = (~agree[b]).nonzero()
         if len(bad):
-            assert float(margins[b, int(bad[0])]) < 1e-2, (b, int(bad[0]), float(margins[b, int(bad[0])]))
+            assert float(margins[b, int(bad[0])]) < 2e-2, (b, int(bad[0]), float(margins[b, int(bad[0])]))
 
 
 @pytest.mark.parametrize("tiny", [True, False], ids=["tiny", "full_size_6s_segment"])
@@ -250,3 +251,31 @@ def test_rearm_after_a_single_failed_step_never_accepts_stale_granules(monkeypat
     assert eng.decode_variant() == 3, "not back on the one-launch step"
     assert torch.equal(toks.long(), ref_t), "the first re-armed steps accepted stale hand-off values"
     eng.close()
+
+
+def test_conditioning_side_stream_never_overlaps_a_one_launch_step():
+    """VERDICT round 5, item 8 (residency before issue): the one-launch steps need all 256 workgroups resident; the reference speaker's
+    mel + Perceiver chain on the side stream (GenVCModel.get_gpt_cond_latents_async) would take CUs away -- a ~0.2 s bounded spin and a
+    fallback.  A GPT call issued while that chain is in flight now waits for it first (GptEngine.watch_stream): 200 rounds of "start the
+    conditioning chain, generate at once without joining": no hand-off time-out, the same ids every time, the one-launch step throughout."""
+    m = _model(False, 1, max_new=12)
+    eng = m.gpt.engine
+    ref = synth.synth_audio(100, "ref", 72000).to(DEV)
+    cond = m.get_gpt_cond_latents(ref, 24000)
+    codes = synth.integers(5, "content_codes", (1, 13), 256).to(DEV)
+    want = m.gpt.generate(cond, codes, **GREEDY_KW)
+    assert eng.decode_variant() == 3
+    torch.cuda.synchronize()
+    before = eng.side_joins
+    for i in range(200):
+        fut = m.get_gpt_cond_latents_async(ref, 24000)
+        got = m.gpt.generate(cond, codes, **GREEDY_KW)              # no fut.result(): the engine itself has to keep the two apart
+        assert torch.equal(got, want), f"round {i}"
+        c2 = fut.result()
+    torch.cuda.synchronize()
+    eng.health()                                                    # raises after a hand-off time-out
+    assert eng.decode_variant() == 3 and m.gpt.recoveries == 0
+    assert eng.side_joins - before >= 100, eng.side_joins - before   # the chain was really in flight when the GPT calls arrived
+    np.testing.assert_allclose(c2.cpu().numpy(), cond.cpu().numpy(), atol=1e-6)
+    del m
+    torch.cuda.empty_cache()

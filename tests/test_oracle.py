@@ -325,3 +325,36 @@ def test_harness_vs_the_references_own_functions(gold, tag, case):
     st = O.synthesize_utt_streaming(W, src, ref, seg_len=1.0, stream_chunk_size=8)
     ns = O.synthesize_utt(W, src, ref, seg_len=1.0)
     check_harness_result(g, case, st, ns, 1e-4, 1e-4)
+
+
+def test_third_party_pins_when_present(gold):
+    """oracle/pin_third_party.py writes mel.npz / resample.npz (torchaudio) and hubert_fairseq.npz (fairseq) where those wheels exist;
+    this container has neither, so the files are absent and the three stages stay pinned to their published algorithms.
+    Whoever runs the recipe gets the checks for free."""
+    import os
+    from conftest import GOLD
+    from genvc_amd.utils import DEFAULT_MEL_NORM_FILE, load_mel_norms
+    ran = 0
+    if os.path.exists(os.path.join(GOLD, "mel.npz")):
+        g = gold("mel")
+        norms = torch.from_numpy(load_mel_norms(DEFAULT_MEL_NORM_FILE))
+        np.testing.assert_allclose(O.mel_spectrogram(synth.synth_audio(100, "ref", 72000), norms).numpy(), g["mel"], atol=1e-4)
+        ran += 1
+    if os.path.exists(os.path.join(GOLD, "resample.npz")):
+        g = gold("resample")
+        for o, n in ((96000, 16000), (96000, 24000), (22050, 16000), (16000, 24000)):
+            x = synth.synth_audio(3, "rs", 6000 * o // 16000)
+            np.testing.assert_allclose(O.resample(x, o, n).numpy(), g[f"y_{o}_{n}"], atol=2e-5)
+        ran += 1
+    if os.path.exists(os.path.join(GOLD, "hubert_fairseq.npz")):
+        g = gold("hubert_fairseq")
+        w = synth.make_weights(17, synth.hubert_weight_spec(gcfg.DEFAULT_HUBERT))
+        tail = torch.zeros(1, 5120)
+        tail[:, :2000] = synth.synth_audio(41, "tail", 2000)
+        hole = synth.synth_audio(43, "hole", 16000).clone()
+        hole[:, 6000:9000] = 0.0
+        for name, wav in (("plain", synth.synth_audio(17, "wav16000", 16000)), ("zero_tail", tail), ("interior_silence", hole)):
+            np.testing.assert_allclose(O.hubert_extract_features(w, gcfg.DEFAULT_HUBERT, wav).numpy(), g[name], atol=2e-4)
+        ran += 1
+    if ran == 0:
+        pytest.skip("torchaudio / fairseq fixtures absent: mel, resampler and ContentVec stay pinned to their published algorithms")
