@@ -123,6 +123,7 @@ class Workload:
         self.fin = torch.zeros(S, device=device, dtype=torch.int32)
         self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         self.keep_codes = None                        # a list: utterance() appends the content codes of every chunk (parity_in_bench)
+        self.stage_ev = None                          # a list: utterance() appends (name, event) marks around its stages (stage_times)
         self.t_first = None                           # host clock at the first 8-token group of a `sync_first` utterance
 
     def utterance(self, u, record=False, sync_first=False):
@@ -134,9 +135,16 @@ class Workload:
         cond_future = m.get_gpt_cond_latents_async(self.ref[u % 4], 24000)
         cond = None
         src = self.src[u % 4]
+        def mark(name):
+            if self.stage_ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.stage_ev.append((name, e))
+        mark("start")
         for c in range(self.n_chunks):
             feat = m.content_extractor.extract_content_features(src[c])                # ContentVec [S,49,256]
             codes = m.content_dvae._engine.encode(feat, frames_major=True)             # DVAE + VQ (int32 [1,13])
+            mark("contentvec+dvae")
             if self.keep_codes is not None:
                 self.keep_codes.append(codes.clone())
             if cond is None:
@@ -150,14 +158,17 @@ class Workload:
             self.fin.zero_()
             # prefix caching: the 32 conditioning rows of chunk 0 stay in the KV cache for the utterance's other chunks
             eng.prefill(self.slots, prefix, want_outputs=False, n_cached=32 if c > 0 else 0)
+            mark("cond join + prefix + prefill (first chunk)" if c == 0 else "prefix + cached prefill")
             base = c * STEPS_PER_CHUNK
             tok_view = self.toks[:, base:base + STEPS_PER_CHUNK]
             lat_view = self.lats[:, base:base + STEPS_PER_CHUNK]
             for g in range(0, STEPS_PER_CHUNK, GROUP):
                 eng.generate(self.slots, self.ids, self.ids_len, self.fin, self.sp, g, GROUP, tok_view, lat_view,
                              max_keys=self.P + 1 + g + GROUP)
+                mark("decode steps")
                 # vocoder every 8 tokens (x4 interpolation + HiFi-GAN -> 8192 samples), inference_utils.py:195-205
                 self.wav = m.hifigan.forward_latents(lat_view[:, g:g + GROUP], 4)
+                mark("vocoder")
                 if record and c == 0 and g == 0:
                     self.ev[1].record()                                                # first 8-token group done
                 if sync_first and c == 0 and g == 0:
@@ -176,6 +187,19 @@ def _cpu_model():
     except OSError:
         pass
     return platform.processor() or platform.machine()
+
+
+def stage_times(wl, u=0):
+    """ms per stage of one utterance (HIP events between the stages of Workload.utterance, summed by stage)"""
+    wl.stage_ev = []
+    wl.utterance(u)
+    torch.cuda.synchronize()
+    ev, wl.stage_ev = wl.stage_ev, None
+    out = {}
+    for (_, e0), (name, e1) in zip(ev[:-1], ev[1:]):
+        out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+    out["total"] = ev[0][1].elapsed_time(ev[-1][1])
+    return out
 
 
 def cpu_baseline(wl, budget_s=10.0, gpu=None):
@@ -535,6 +559,7 @@ def streams_leg(device, rank, streams=8, weights="bf16_act", steps=3, parity=Tru
                         "frac": by / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                         "bytes_per_launch": by,
                         "kernel": f"{kname} (one decode step of {streams} streams, sampler + head launches included in the time)"}}
+    out["stages_ms_per_utterance"] = stage_times(wl)
     if parity:
         out["parity"] = streams_parity(wl, weights)
     del wl
@@ -906,6 +931,7 @@ def main():
                          "decode_step_us_launch_per_phase": whole_us},
             "kernels": kern,
         }
+        out["stages_ms_per_utterance"] = stage_times(wl)
         if offline is not None:
             out["offline"] = offline
             out["offline_utts_per_s"] = offline["offline_utts_per_s"]
