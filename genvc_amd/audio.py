@@ -1,8 +1,8 @@
 """Audio I/O of the CLI ("next"): `load_audio` with the reference's checks
 (/root/reference/utils.py:49-75) without torchaudio.  WAV PCM 16/24/32-bit and float32 are read with the
-standard library; resampling restates torchaudio.functional.resample's default
-(sinc_interp_hann, lowpass_filter_width=6, rolloff=0.99) in plain torch.  Not part of the timed hot path."""
-import math
+standard library; resampling (torchaudio.functional.resample's default: sinc_interp_hann, lowpass_filter_width=6,
+rolloff=0.99) runs on the HIP kernel gvc_resample -- there is no CPU resampler in the product tree (the float64 restatement
+that checks the kernel lives in oracle/).  Not part of the timed hot path."""
 import struct
 import wave
 
@@ -44,42 +44,22 @@ def read_wav(path):
     return torch.from_numpy(x.reshape(-1, ch).T.copy()), sr
 
 
-def resample(wav, orig, new, lowpass_filter_width=6, rolloff=0.99):
-    """torchaudio.functional.resample(..., resampling_method="sinc_interp_hann") semantics"""
-    if orig == new:
-        return wav
-    g = math.gcd(int(orig), int(new))
-    o, n = int(orig) // g, int(new) // g
-    base = min(o, n) * rolloff
-    width = math.ceil(lowpass_filter_width * o / base)
-    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
-    t = torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx
-    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
-    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
-    t = t * math.pi
-    kern = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base / o)
-    kern = kern.to(wav.dtype).to(wav.device)
-    length = wav.shape[-1]
-    x = torch.nn.functional.pad(wav[:, None], (width, width + o))
-    y = torch.nn.functional.conv1d(x, kern, stride=o)                      # [C, n, frames]
-    y = y.transpose(1, 2).reshape(wav.shape[0], -1)
-    return y[..., :math.ceil(n * length / o)]
-
-
 def load_audio(audiopath, sampling_rate, device=None):
-    """reference utils.py:49-75: mono mix, resample, range sanity checks, clip to [-1, 1]; None on failure.
-    With a CUDA `device` the resampling runs on the HIP kernel (gvc_resample); without one, on the torch restatement."""
+    """reference utils.py:49-75: mono mix, resample, range sanity checks, clip to [-1, 1]; None on failure (the reference
+    prints and returns None).  Resampling runs on the HIP kernel (gvc_resample) on `device` (default: the current CUDA device);
+    a file that needs resampling without a GPU is a failure like any other: no CPU fallback."""
     try:
         audio, lsr = read_wav(audiopath)
         if audio.size(0) != 1:
             audio = torch.mean(audio, dim=0, keepdim=True)
         assert audio.size(1) > 10
         if lsr != sampling_rate:
-            if device is not None and str(device).startswith("cuda"):
-                from .engine import resample as hip_resample
-                audio = hip_resample(audio.to(device).contiguous(), lsr, sampling_rate).cpu()
-            else:
-                audio = resample(audio, lsr, sampling_rate)
+            if device is None or not str(device).startswith("cuda"):
+                if not torch.cuda.is_available():
+                    raise RuntimeError(f"resampling {lsr} -> {sampling_rate} Hz needs the HIP library and a GPU (no CPU fallback)")
+                device = "cuda"
+            from .engine import resample as hip_resample
+            audio = hip_resample(audio.to(device).contiguous(), lsr, sampling_rate).cpu()
     except Exception as e:                                                   # noqa: BLE001 (mirrors the reference)
         print(f"Error with {audiopath}. {e}")
         return None

@@ -200,7 +200,8 @@ def test_hubert_padding_mask_semantics():
 def test_resampler_restatement_on_band_limited_signals(orig, new):
     """row f2 (torchaudio absent: parity unpinned against torchaudio itself): the float64 restatement of its sinc_interp_hann
     recipe reproduces a band-limited signal sampled at the new rate (interior, filter ripple), agrees with
-    scipy.signal.resample_poly -- another low-pass design -- to the two filters' ripple, has torchaudio's output length and is linear"""
+    scipy.signal.resample_poly -- another low-pass design -- to the two filters' ripple, has torchaudio's output length and is linear
+    (the product has no CPU resampler: genvc_amd/audio.py resamples on the HIP kernel, which tests/test_gpu_frontend.py checks against this oracle)"""
     import math
     from scipy.signal import resample_poly
     T = 6000 * orig // 16000
@@ -218,12 +219,10 @@ def test_resampler_restatement_on_band_limited_signals(orig, new):
     sp = resample_poly(x, new // g, orig // g)
     m = min(len(sp), n_out)
     assert np.abs(y[edge:m - edge] - sp[edge:m - edge]).max() < 5e-3
-    # linearity and the product's CPU loader path (an independent torch restatement: conv1d over the same kernel)
-    from genvc_amd.audio import resample as loader_resample
+    # linearity
     x2 = synth.synth_audio(3, "rs", T)
     a = O.resample(x2, orig, new)
     np.testing.assert_allclose(O.resample(2.5 * x2, orig, new).numpy(), 2.5 * a.numpy(), atol=1e-6)
-    np.testing.assert_allclose(loader_resample(x2, orig, new).numpy(), a.numpy(), atol=1e-6)
 
 
 def test_streaming_chain_full_size_vs_reference_classes(gold):
