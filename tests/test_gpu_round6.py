@@ -279,3 +279,34 @@ def test_conditioning_side_stream_never_overlaps_a_one_launch_step():
     np.testing.assert_allclose(c2.cpu().numpy(), cond.cpu().numpy(), atol=1e-6)
     del m
     torch.cuda.empty_cache()
+
+
+def test_config4_decode_shape_topk50_vs_oracle():
+    """BASELINE configs[4]'s real decode shape: 5 streams (the five 6 s segments of a 30 s source), Tc = 75 (110-row prefill, contexts 110 ->
+    251 keys: the rows step's 2 / 4 key-chunk splits), top_k = 50, 141 sampled steps at full depth -- the graph-replayed loop (sampler kernel:
+    bitonic sort, top-k threshold, top-p scan, inverse-CDF draw from the shared counter RNG) against the oracle's loop (reference
+    layers/stream_generator.py:809-881 with HF's processors' semantics).  A draw within float rounding of a CDF boundary may differ and
+    the sequences part there; everything before must agree, and at least 100 steps of every stream do."""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    from test_gpu_gpt import run_generate
+    torch.cuda.empty_cache()
+    dims = gcfg.gpt_dims(gcfg.DEFAULT_MODEL_ARGS)
+    w = synth.make_weights(1, synth.gpt_weight_spec(dims), device=DEV)
+    eng = GptEngine(dims, max_slots=8, max_rows=2048)
+    eng.bind(w)
+    wc = {k: v.cpu() for k, v in w.items()}
+    samp = dict(gcfg.DEFAULT_SAMPLING, top_k=50)
+    B, Tc, n = 5, 75, 141
+    cond = synth.uniform(77, "cond_latents", (1, 32, 1024), 1.0).expand(B, -1, -1).contiguous()
+    codes = synth.integers(77, "content_codes", (B, Tc), 256)
+    _, toks, lats = run_generate(eng, dims, cond, codes, n, sampling=samp, seed=17, group=48)
+    assert eng.decode_variant() == 5
+    ref_t, ref_l, _ = O.generate(wc, dims, cond, codes, samp, max_new=n, seed=17, stop_on_eos=False)
+    m = min(toks.shape[1], ref_t.shape[1])
+    agree = toks[:, :m].long() == ref_t[:, :m]
+    first = [int((~agree[b]).nonzero()[0]) if (~agree[b]).any() else m for b in range(B)]
+    assert min(first) >= 100, first
+    k = min(first)
+    np.testing.assert_allclose(lats[:, :k].numpy(), ref_l[:, :k].numpy(), atol=3e-4)
+    eng.close()
