@@ -56,6 +56,7 @@ _SIGNATURES = {
     "gvc_gpt_prefix_embeddings": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "gvc_gpt_prefill": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "gvc_gpt_prefill_cached": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "gvc_gpt_prefill_cond": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "gvc_gpt_decode_step": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P]),
     "gvc_gpt_reset_slots": (C.c_int, [_P, _P, C.c_int32, _P]),
     "gvc_gpt_latents": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

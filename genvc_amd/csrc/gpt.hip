@@ -1406,6 +1406,28 @@ extern "C" int gvc_gpt_prefill_cached(gvc_gpt* c, const int32_t* slots, int32_t 
     return GVC_OK;
 }
 
+// The conditioning rows alone (no text rows, no start token, no head): K/V of rows 0..n_cond-1 into the slots' caches, length n_cond.
+// For callers that know the target speaker before the first source segment arrives (a streaming session: the reference recomputes these
+// rows inside every segment's prefill, inference_utils.py:43-66): every segment, the first one too, then takes gvc_gpt_prefill_cached with
+// n_cached = n_cond.  Same kernels and per-row arithmetic as the rows of a full prefill (each row's projections depend on that row only,
+// its attention on the rows in front of it).
+extern "C" int gvc_gpt_prefill_cond(gvc_gpt* c, const int32_t* slots, int32_t B, const float* cond_latents, int32_t n_cond, gvc_stream sv) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const int d = c->dm.d_model;
+    GVC_REQUIRE(B >= 1 && B <= c->dm.max_slots && n_cond >= 1 && B * n_cond <= c->dm.max_rows && n_cond < c->dm.max_seq, GVC_ERR_ARG,
+                "prefill_cond: bad B=%d n_cond=%d", B, n_cond);
+    hipStream_t s = (hipStream_t)sv;
+    hipLaunchKernelGGL(k_embed_rows, dim3(B * n_cond), dim3(256), 0, s, c->x, cond_latents, B, n_cond, n_cond, d, c->mel_emb, c->mel_pos,
+                       (const int32_t*)nullptr, 0, 0, 0, 0);
+    GVC_LAUNCH_CHECK();
+    c->rows_keys_hint = n_cond;
+    if ((rc = run_rows(c, slots, B, n_cond, s))) return rc;
+    hipLaunchKernelGGL(k_set_state, dim3(cdiv(B, 64)), dim3(64), 0, s, c->st, slots, B, n_cond, 0);
+    GVC_LAUNCH_CHECK();
+    return GVC_OK;
+}
+
 extern "C" int gvc_gpt_latents(gvc_gpt* c, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
                                const int32_t* gen_codes, int32_t n, int32_t start_tok, int32_t stop_tok, float* out,
                                gvc_stream sv) {

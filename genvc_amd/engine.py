@@ -102,6 +102,13 @@ class GptEngine:
                                            self.dims["start_audio_token"], ptr(logits), ptr(latent), stream()), "prefill")
         return logits, latent
 
+    def prefill_cond(self, slots, cond_latents):
+        """the conditioning rows alone into the slots' KV caches (include/genvc_hip.h: gvc_gpt_prefill_cond): later prefills of these slots
+        pass n_cached = cond_latents.shape[1]"""
+        self._join_side()
+        B, n, _ = cond_latents.shape
+        check(lib().gvc_gpt_prefill_cond(self._h, ptr(_i32(slots)), B, ptr(_f32(cond_latents)), n, stream()), "prefill_cond")
+
     def decode_step(self, slots, tok, logits=None, latent=None):
         self._join_side()
         B = slots.shape[0]

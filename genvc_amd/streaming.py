@@ -48,12 +48,13 @@ class _Session:
 
 
 class StreamSessions:
-    def __init__(self, model, max_sessions=8, group=8, left_context_s=0.0, rearm_after_s=5.0, rearm_max_tries=3):
+    def __init__(self, model, max_sessions=8, group=8, left_context_s=0.0, rearm_after_s=5.0, rearm_max_tries=3, prefill_speaker=True):
         m = self.m = model
         self.ctx = int(round(left_context_s * model.content_sample_rate / 320.0)) * 320       # whole ContentVec hops
         g = m.gpt
         g._need_engine()
         self.eng = g.engine
+        self.prefill_speaker = bool(prefill_speaker)
         self.group = group
         self.max_new = g.max_gen_mel_tokens
         self.free = list(range(max_sessions))
@@ -89,7 +90,13 @@ class StreamSessions:
         cond = self.m.get_gpt_cond_latents(ref_audio.to(self.m.device), self.m.config.audio.sample_rate)
         sid = self._next_id
         self._next_id += 1
-        self.sessions[sid] = _Session(self.free.pop(0), cond)
+        s = self.sessions[sid] = _Session(self.free.pop(0), cond)
+        if self.prefill_speaker:
+            # the speaker is known before the first source segment arrives: its 32 conditioning rows go into the slot's KV cache NOW
+            # (gvc_gpt_prefill_cond), so the first segment too computes only its text rows + start token -- the first audio chunk of a
+            # session no longer waits for them (the reference rebuilds them in every segment's prefill, inference_utils.py:43-66)
+            self.eng.prefill_cond(torch.tensor([s.slot], device=self.m.device, dtype=torch.int32), cond.to(torch.float32).contiguous())
+            s.prefilled = True
         return sid
 
     def push(self, sid, src_segment):

@@ -128,6 +128,11 @@ int gvc_gpt_prefill(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* 
  * the cache contents. */
 int gvc_gpt_prefill_cached(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* prefix_emb, int32_t P,
                            int32_t n_cached, int32_t start_tok, float* logits_out, float* latent_out, gvc_stream s);
+/* The conditioning rows alone: K/V of cond_latents[b] (n_cond rows, [B, n_cond, d]) into the caches of slots[b], length n_cond; no text
+ * rows, no start token, no outputs.  For a caller that knows the target speaker before the first source segment arrives (a streaming
+ * session; the reference rebuilds these rows inside every segment's prefill, inference_utils.py:43-66): every segment, the first one too,
+ * then calls gvc_gpt_prefill_cached with n_cached = n_cond and its first audio chunk no longer waits for the 32 conditioning rows. */
+int gvc_gpt_prefill_cond(gvc_gpt* ctx, const int32_t* slots, int32_t B, const float* cond_latents, int32_t n_cond, gvc_stream s);
 
 /* One KV-cached decode step for B streams (gpt_inference.py:92-112):
  * x = mel_embedding[tok_in[b]] + mel_pos[pos(slot)], 30 blocks against the cache, double

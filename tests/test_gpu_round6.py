@@ -310,3 +310,39 @@ def test_config4_decode_shape_topk50_vs_oracle():
     k = min(first)
     np.testing.assert_allclose(lats[:, :k].numpy(), ref_l[:, :k].numpy(), atol=3e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("L,B", [(2, 1), (30, 1), (2, 3)], ids=["two_layers", "full_depth", "three_streams"])
+def test_prefill_cond_then_cached_prefill_equals_the_full_prefill(L, B):
+    """gvc_gpt_prefill_cond (a streaming session registers its speaker before the source arrives: the 32 conditioning rows go into the KV
+    cache alone; the reference rebuilds them inside every segment's prefill, inference/inference_utils.py:43-66, gpt_inference.py:81-91):
+    the first segment's prefill then computes 16 rows instead of 48.  Logits / latent of that cached prefill and of the decode steps behind
+    it against the full prefill on fresh slots (<= 5e-5: the same rows through the same kernels) and against the oracle."""
+    from genvc_amd.engine import GptEngine
+    from oracle import genvc_oracle as O
+    torch.cuda.empty_cache()
+    dims = gcfg.gpt_dims(dict(gcfg.DEFAULT_MODEL_ARGS, gpt_layers=L))
+    w = synth.make_weights(3, synth.gpt_weight_spec(dims), device=DEV)
+    eng = GptEngine(dims, max_slots=8, max_rows=2048)
+    eng.bind(w)
+    wc = {k: v.cpu() for k, v in w.items()}
+    cond = synth.uniform(91, "cond_latents", (B, 32, 1024), 1.0)
+    codes = synth.integers(91, "codes", (B, 13), 256)
+    s_sess = torch.arange(B, device=DEV, dtype=torch.int32)
+    s_full = s_sess + 4
+    eng.prefill_cond(s_sess, cond.to(DEV))
+    prefix = eng.prefix_embeddings(cond.to(DEV), codes.to(DEV).int())
+    lg_c, lat_c = eng.prefill(s_sess, prefix, n_cached=32)
+    lg_f, lat_f = eng.prefill(s_full, prefix)
+    z, logits, cache = O.gpt_prefill(wc, dims, O.compute_embeddings(wc, dims, cond, codes)[0])
+    np.testing.assert_allclose(lg_c.cpu().numpy(), lg_f.cpu().numpy(), atol=5e-5)
+    np.testing.assert_allclose(lg_c.cpu().numpy(), logits.numpy(), atol=1e-4)
+    np.testing.assert_allclose(lat_c.cpu().numpy(), z.numpy(), atol=1e-4)
+    tok = torch.tensor([5, 900, 77][:B], device=DEV, dtype=torch.int32)
+    for j in range(1, 4):
+        a = eng.decode_step(s_sess, tok)
+        b = eng.decode_step(s_full, tok)
+        z, logits, cache = O.gpt_decode_step(wc, dims, cache, tok.cpu().long(), j)
+        np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), atol=5e-5)
+        np.testing.assert_allclose(a[0].cpu().numpy(), logits.numpy(), atol=1e-4)
+    eng.close()
