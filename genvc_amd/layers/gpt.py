@@ -106,7 +106,8 @@ class GPT(nn.Module):
 
     def init_gpt_for_inference(self, kv_cache=True, use_deepspeed=False, max_slots=8, max_rows=4096, weight_dtype="fp32"):
         """reference gpt.py:197-218: here = create the HIP context and repack the weights into it.
-        weight_dtype: "fp32" (reference numerics), "bf16" (bf16 weight storage) or "bf16_kv" (+ bf16 KV cache)."""
+        weight_dtype: "fp32" (reference numerics), "bf16" (bf16 weight storage), "bf16_kv" (+ bf16 KV cache) or "bf16_act" (+ bf16
+        activations across the hand-offs of the one-launch rows step: include/genvc_hip.h, weight_dtype 3)."""
         if not kv_cache:
             raise NotImplementedError("the HIP path always uses the KV cache")
         if use_deepspeed:

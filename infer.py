@@ -27,7 +27,7 @@ if __name__ == "__main__":
     parser.add_argument("--synthetic", action="store_true", help="deterministic synthetic weights instead of --model_path")
     parser.add_argument("--tiny", action="store_true", help="with --synthetic: the 2-layer test architecture")
     parser.add_argument("--save_tokens", type=str, default=None)
-    parser.add_argument("--weights", type=str, default="fp32", choices=["fp32", "bf16", "bf16_kv"],
+    parser.add_argument("--weights", type=str, default="fp32", choices=["fp32", "bf16", "bf16_kv", "bf16_act"],
                         help="GPT weight / KV-cache storage on the GPU (fp32 = the reference's numerics)")
     args = parser.parse_args()
 
