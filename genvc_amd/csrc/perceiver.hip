@@ -97,8 +97,11 @@ struct gvc_perceiver {
 extern "C" int gvc_perceiver_create(const gvc_perceiver_dims* dims, gvc_perceiver** out) {
     GVC_REQUIRE(dims && out, GVC_ERR_ARG, "gvc_perceiver_create: null argument");
     const gvc_perceiver_dims& D = *dims;
-    GVC_REQUIRE(D.dim % 256 == 0 && D.dim_head == 64 && D.heads >= 1 && D.depth >= 1 && D.num_latents == 32,
-                GVC_ERR_UNSUPPORTED, "perceiver: need dim %% 256 == 0, dim_head == 64 and 32 latents");
+    // (the latent rows live fragment-major in 16-row tiles and share one skinny GEMM of <= 128 rows per group of batch elements: any
+    //  multiple of 16 up to 64 latents; GenVC's config fixes 32, gpt.py:163-170)
+    GVC_REQUIRE(D.dim % 256 == 0 && D.dim_head == 64 && D.heads >= 1 && D.depth >= 1 && D.num_latents >= 16 && D.num_latents <= 64 &&
+                    D.num_latents % 16 == 0,
+                GVC_ERR_UNSUPPORTED, "perceiver: need dim %% 256 == 0, dim_head == 64 and 16 / 32 / 48 / 64 latents");
     GVC_REQUIRE((D.dim_head * D.heads) % 128 == 0, GVC_ERR_UNSUPPORTED, "perceiver: heads x dim_head must be a multiple of 128");
     auto* c = new gvc_perceiver();
     c->dm = D;
@@ -311,8 +314,9 @@ static int perc_launch(gvc_perceiver* c, int B, int F, hipStream_t s) {
             GVC_LAUNCH_CHECK();
         }
         // the latent path below takes the batch in groups of at most 128 rows (the skinny GEMM's eight M tiles)
-        for (int b0 = 0; b0 < B; b0 += 4) {
-            const int M = (B - b0 < 4 ? B - b0 : 4) * NL;
+        const int gb = 128 / NL;                            // batch elements per group: 8 / 4 / 2 / 2 at 16 / 32 / 48 / 64 latents
+        for (int b0 = 0; b0 < B; b0 += gb) {
+            const int M = (B - b0 < gb ? B - b0 : gb) * NL;
             float* Xg = c->X + (size_t)b0 * NL * d;
             // latents += o @ to_out^T
             skinny(c->o + (size_t)b0 * NL * in, M, ly.f_out, d, in, Xg, d);

@@ -10,7 +10,7 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 streams = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-wl = bench.Workload("cuda:0", 0, streams)
+wl = bench.Workload("cuda:0", 0, streams, os.environ.get("WEIGHTS", "fp32"), max_slots=max(8, streams))      # WEIGHTS=bf16_act: the bf16-activation rows step
 proc = psutil.Process()
 ref = {}
 t0 = time.time()
@@ -25,4 +25,5 @@ for u in range(n):
     if u % 20 == 0 or u == n - 1:
         free, total = torch.cuda.mem_get_info()
         print(f"utt {u:4d}  free HBM {free / 2**20:10.1f} MiB  host RSS {proc.memory_info().rss / 2**20:8.1f} MiB  {time.time() - t0:6.1f} s", flush=True)
+wl.eng.health()
 print("ok")
