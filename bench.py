@@ -187,6 +187,20 @@ class Workload:
         return self.toks
 
 
+def _guarded(name, fn):
+    """an auxiliary leg must never cost the headline line: its failure is recorded in its place (and on stderr)"""
+    try:
+        return fn()
+    except Exception as e:                                   # noqa: BLE001
+        import traceback
+        print(f"bench.py: leg `{name}` failed: {type(e).__name__}: {e}\n{traceback.format_exc()}", file=sys.stderr)
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                    # noqa: BLE001
+            pass
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -569,7 +583,7 @@ def streams_leg(device, rank, streams=8, weights="bf16_act", steps=3, parity=Tru
                         "kernel": f"{kname} (one decode step of {streams} streams, sampler + head launches included in the time)"}}
     out["stages_ms_per_utterance"] = stage_times(wl)
     if parity:
-        out["parity"] = streams_parity(wl, weights)
+        out["parity"] = _guarded("streams8 parity", lambda: streams_parity(wl, weights))
     del wl
     torch.cuda.empty_cache()
     return out
@@ -724,7 +738,7 @@ def config4_leg(wl, rank, world, dist, device, steps=3, parity=True):
             "prefill_mfma_frac": fl_prefill / (st[2] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "perceiver_mfma_frac_incl_mel": fl_perc / (st[0] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
             "decode_step_us": st[3] / c4.n_new * 1e3, "decode_variant": wl.eng.decode_variant(),
-            "parity": config4_parity(c4) if parity and rank == 0 else None}
+            "parity": _guarded("config4 parity", lambda: config4_parity(c4)) if parity and rank == 0 else None}
 
 
 def cold_probe(device, rank, weights, max_slots):
@@ -979,16 +993,16 @@ def main():
                          "decode_step_us_launch_per_phase": whole_us},
             "kernels": kern,
         }
-        out["stages_ms_per_utterance"] = stage_times(wl)
+        out["stages_ms_per_utterance"] = _guarded("stage_times", lambda: stage_times(wl))
         if offline is not None:
             out["offline"] = offline
             out["offline_utts_per_s"] = offline["offline_utts_per_s"]
         if config4 is not None:
             out["config4"] = config4
         if do_extra and world == 1:
-            out["prefill_5x110"] = prefill_leg(wl)
+            out["prefill_5x110"] = _guarded("prefill_5x110", lambda: prefill_leg(wl))
         if headline and not args.no_harness:
-            out["harness"] = harness_leg(wl)
+            out["harness"] = _guarded("harness", lambda: harness_leg(wl))
         if cold is not None:
             out["cold_start"] = cold
             out["cold_first_chunk_latency_ms"] = cold["cold_first_chunk_latency_ms"]
@@ -1000,17 +1014,19 @@ def main():
                 torch.cuda.synchronize()
                 gpu = (g_toks.cpu(), wl.keep_codes)
                 wl.keep_codes = None
-            cb = cpu_baseline(wl, gpu=gpu)
-            out["parity_in_bench"] = cb.pop("parity")
+            cb = _guarded("cpu_baseline", lambda: cpu_baseline(wl, gpu=gpu))
+            out["parity_in_bench"] = cb.pop("parity", None)
             out["cpu_baseline"] = cb
         if do_extra and world == 1:
             # BASELINE configs[3]: bf16 weights + KV cache + bf16 activations across the rows step's hand-offs (weight_dtype 3), with its parity
             # block; beside it the same leg with fp32 activations (weight_dtype 2: what this key measured up to round 5)
-            leg = streams_leg(device, rank, weights="bf16_act", parity=not args.no_cpu_baseline)
-            ref2 = streams_leg(device, rank, weights="bf16_kv", parity=False)
-            leg["fp32_activations_bf16_kv"] = {k: ref2[k] for k in ("utts_per_s", "decode_step_us", "first_chunk_latency_ms", "decode_variant")}
-            leg["fp32_activations_bf16_kv"]["roofline_frac"] = ref2["roofline"]["frac"]
-            out["streams8_bf16_kv"] = leg
+            def both():
+                leg = streams_leg(device, rank, weights="bf16_act", parity=not args.no_cpu_baseline)
+                ref2 = streams_leg(device, rank, weights="bf16_kv", parity=False)
+                leg["fp32_activations_bf16_kv"] = {k: ref2[k] for k in ("utts_per_s", "decode_step_us", "first_chunk_latency_ms", "decode_variant")}
+                leg["fp32_activations_bf16_kv"]["roofline_frac"] = ref2["roofline"]["frac"]
+                return leg
+            out["streams8_bf16_kv"] = _guarded("streams8_bf16_kv", both)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
