@@ -141,7 +141,10 @@ class Workload:
             self.ev[0].record()
         # mel + Perceiver of the reference speaker on a second stream, beside the first chunk's ContentVec + DVAE (as the harness does:
         # inference_utils.synthesize_utt_streaming; the two chains are independent)
-        cond_future = None if registered else m.get_gpt_cond_latents_async(self.ref[u % 4], 24000)
+        # (enqueued BEHIND the first chunk's ContentVec + DVAE launches, as the harness does: the side stream only waits for `ready`)
+        ready = torch.cuda.Event()
+        ready.record()
+        cond_future = None
         src = self.src[u % 4]
         def mark(name):
             if self.stage_ev is not None:
@@ -156,6 +159,8 @@ class Workload:
             if self.keep_codes is not None:
                 self.keep_codes.append(codes.clone())
             if cond is None:
+                if cond_future is None:
+                    cond_future = m.get_gpt_cond_latents_async(self.ref[u % 4], 24000, after=ready)
                 cond = cond_future.result()
                 if self.S > 1:
                     cond = cond.expand(self.S, -1, -1).contiguous()                    # one reference speaker for the batch

@@ -135,13 +135,22 @@ def synthesize_utt_streaming(genVC_mdl, src_wav, tgt_audio, seg_len=6.0, stream_
     seg = int(seg_len * m.content_sample_rate)
     # the reference computes the conditioning latents first (:152-153); they do not depend on the source, so here their mel + Perceiver
     # chain runs on a second stream beside the first segment's ContentVec + DVAE chain (same arithmetic, shorter first-chunk latency)
-    cond_future = m.get_gpt_cond_latents_async(tgt_audio.to(m.device), m.config.audio.sample_rate) if hasattr(m, "get_gpt_cond_latents_async") else None
-    cond_latent = None if cond_future is not None else m.get_gpt_cond_latents(tgt_audio.to(m.device), m.config.audio.sample_rate)
+    # -- and its ~25 launches are enqueued AFTER the first segment's ContentVec + DVAE launches (the side stream only waits for the uploads):
+    # the GPU starts on the source while the host is still busy with the conditioning chain
+    tgt_dev = tgt_audio.to(m.device)
+    can_async = hasattr(m, "get_gpt_cond_latents_async")
+    uploaded = torch.cuda.Event() if can_async else None
+    if uploaded is not None:
+        uploaded.record()
+    cond_future = None
+    cond_latent = None if can_async else m.get_gpt_cond_latents(tgt_dev, m.config.audio.sample_rate)
     cached = 0          # prefix caching: after the first segment the conditioning rows are already in the KV cache
     for src_seg in segments(src_wav, seg, min_len):
         feat = m.content_extractor.extract_content_features(src_seg)
         codes = m.content_dvae.get_codebook_indices(feat.transpose(1, 2))
         if cond_latent is None:
+            if cond_future is None:
+                cond_future = m.get_gpt_cond_latents_async(tgt_dev, m.config.audio.sample_rate, after=uploaded)
             cond_latent = cond_future.result()
         fake = m.gpt.compute_embeddings(cond_latent, codes)
         gen = m.gpt.get_generator(fake_inputs=fake, num_return_sequences=1, output_attentions=False,

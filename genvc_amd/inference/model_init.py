@@ -81,12 +81,15 @@ class GenVCModel(nn.Module):
             embs.append(self.gpt.get_style_emb(mel, None, frames_major=mel_fm))
         return torch.stack(embs).mean(dim=0).transpose(1, 2).contiguous()
 
-    def get_gpt_cond_latents_async(self, audio, sr, length=30, chunk_length=6):
+    def get_gpt_cond_latents_async(self, audio, sr, length=30, chunk_length=6, after=None):
         """get_gpt_cond_latents on a second HIP stream: the reference speaker's mel + Perceiver chain (~25 short launches) does not
         depend on the source audio, so the streaming harness runs it BESIDE the first segment's ContentVec + DVAE chain instead of
         in front of it (first-chunk latency; the arithmetic and its order inside each chain are unchanged).  Returns a handle whose
-        .result() makes the caller's current stream wait for the latents and returns them."""
-        return _CondFuture(self, audio, sr, length, chunk_length)
+        .result() makes the caller's current stream wait for the latents and returns them.
+        `after` (a torch.cuda.Event on the caller's stream at which `audio` is ready): the side chain waits for THAT instead of for everything
+        the caller's stream holds -- so a caller can enqueue its own first kernels (ContentVec of the first segment) BEFORE spending the
+        ~0.3 ms of host time this chain's ~25 launches take, and the GPU is not idle meanwhile."""
+        return _CondFuture(self, audio, sr, length, chunk_length, after)
 
     @torch.inference_mode()
     def warmup(self, seg_len=1.0, streams=1, ref_seconds=3.0, stream_chunk_size=8, top_k=None, max_new_tokens=None):
@@ -148,14 +151,17 @@ class GenVCModel(nn.Module):
 
 
 class _CondFuture:
-    def __init__(self, model, audio, sr, length, chunk_length):
+    def __init__(self, model, audio, sr, length, chunk_length, after=None):
         if not audio.is_cuda:
             audio = audio.to(model.device)
         main = torch.cuda.current_stream(audio.device)
         side = getattr(model, "_cond_stream", None)
         if side is None:
             side = model._cond_stream = torch.cuda.Stream(device=audio.device)
-        side.wait_stream(main)                       # (the audio may still be in flight on the caller's stream)
+        if after is not None:
+            side.wait_event(after)                   # the audio is ready at `after`; what the caller enqueued behind it runs beside this chain
+        else:
+            side.wait_stream(main)                   # (the audio may still be in flight on the caller's stream)
         audio.record_stream(side)
         with torch.cuda.stream(side):
             self.cond = model.get_gpt_cond_latents(audio, sr, length, chunk_length)
