@@ -1,3 +1,7 @@
+# Same-box A/B of two trees' headline legs (first-chunk latency, utterances/s).  Prepare in the build container (the GPU box has no .git):
+#   mkdir .ab_old && git archive <old commit> bench.py genvc_amd oracle tests/golden __graft_entry__.py include | tar -x -C .ab_old && cp -r genvc_amd/lib .ab_old/genvc_amd/
+#   gpurun -- 'bash scripts/ab_first_chunk.sh'; rm -rf .ab_old
+# Round 6 (conditioning chain enqueued behind the first segment's ContentVec + DVAE): old 7.41 / 7.47 / 7.38 ms, new 7.18 / 7.22 / 7.13 ms.
 mkdir -p gpurun_out
 F="--steps 12 --warmup 3 --no-cpu-baseline --no-offline --no-harness --no-extra --no-cold"
 for i in 1 2 3; do
