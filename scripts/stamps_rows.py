@@ -44,7 +44,7 @@ label = {0: "gathered", 1: "published", 2: "LN merged", 3: "fills ok", 4: "MFMA 
 labelB = {2: "own gathers", 0: "barrier (q ready)", 4: "scores+fold", 5: "partials in LDS", 6: "barrier", 7: "merged", 1: "published"}
 tot = {}
 for p in range(5):
-    ks = order[p]
+    ks = [k for k in order[p] if not np.isnan(W(2, p, k))]          # (the bf16-activation kernel stamps 0, 3, 4, 6, 1 only)
     seg = []
     for a, b in zip(ks[:-1], ks[1:]):
         v = np.nanmean([W(l, p, b) - W(l, p, a) for l in range(2, nl)])
